@@ -1,0 +1,156 @@
+/* libunet_hip.so -- C ABI of the gfx950 (MI355X) kernels for the SaviorDT/UNet hot path.
+ *
+ * The reference (a pure-PyTorch repository) has no FFI of its own: the operations below are
+ * the ATen calls its nn.Module / loss code dispatches, cited per entry point as
+ * reference file:line.  Every function
+ *   - takes plain device pointers and sizes (no framework types),
+ *   - allocates nothing, keeps no global mutable state, never synchronises the device,
+ *   - enqueues its kernels on `stream` (a hipStream_t passed as void*),
+ *   - returns UH_OK or a negative uh_status; uh_last_error() gives the thread-local message.
+ *
+ * Activation layout ("padded-linear NHWC", bf16): a logical [B][H][W][C] tensor is stored as
+ * Mp = B*(H+1)*(W+1) rows of C channels, row m = (b*(H+1)+y)*(W+1)+x; rows with y==H or x==W
+ * are zero, and uh_guard_rows(W) zero rows precede row 0 and follow row Mp-1.  Pointers passed
+ * here address row 0.  `cstride`/`coff` select a channel window of a wider buffer (skip concat).
+ */
+#ifndef UNET_HIP_H
+#define UNET_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { UH_OK = 0, UH_ERR_SHAPE = -1, UH_ERR_HIP = -2, UH_ERR_UNSUPPORTED = -3 } uh_status;
+typedef void* uh_stream;
+
+const char* uh_last_error(void);
+int uh_version(void);
+/* zero guard rows required on each side of a padded-linear buffer of image width W */
+int uh_guard_rows(int W);
+/* rowmask[m] = 1 for interior rows, 0 for pad rows; m in [0, Mp) */
+int uh_rowmask_build(int B, int H, int W, uint8_t* rowmask, uh_stream s);
+
+/* ---- weight packing -------------------------------------------------------------------
+ * Generic fp32 -> bf16 repack: dst[n*on + t*ot + k] = src[n*sn + tmap(t)*st + k*sk],
+ * tmap(t) = reverse ? T-1-t : t.  Turns OIHW conv weights (unet.py:19-76), [Cin][Cout][2][2]
+ * transposed-conv weights (unet.py:51-72) and 2x2/1x1 conv weights (lunext.py:67-185) into
+ * the [N][T][K] GEMM operand the MFMA kernels read, for forward and for dgrad (reverse=1
+ * gives the 180-degree rotated filter). */
+int uh_pack_weights(const float* src, void* dst_bf16, int N, int T, int K,
+                    long long sn, long long st, long long sk, long long on, long long ot,
+                    int reverse, uh_stream s);
+
+/* ---- implicit-GEMM convolution (MFMA bf16, fp32 accumulate) ----------------------------
+ * out[m][n] = sum_{t<T} sum_{k<K} a[m + off(t)][k] * w[n][t][k]   (T = 9: off = (ty-1)*(W+1)+(tx-1); T = 1: off = 0)
+ * Replaces nn.Conv2d 3x3 pad 1 forward (unet.py:99-169), its input gradient (autograd of the same,
+ * with rotated weights), nn.ConvTranspose2d k2 s2 (unet.py:132,144,154,164; lunext.py:223-249) as a
+ * T=1 GEMM with a pixel-shuffle store, and 1x1 / 2x2-stride-2 convs after space-to-depth (lunext.py).
+ * K and N must be multiples of 64.  Epilogue modes: */
+enum {
+  UH_EPI_RAW_STATS = 0,   /* out = bf16(acc + bias), zero on pad rows; per-M-tile channel sums of v and v*v
+                             over interior rows -> stat_partial[mtile][2][N]   (train-mode BN input) */
+  UH_EPI_AFFINE_RELU = 1, /* out = relu(acc*scale[n] + shift[n]) on interior rows, 0 on pads (eval-mode BN folded) */
+  UH_EPI_MASKED = 2,      /* out = acc (+bias if given) on interior rows, 0 on pads (dgrad, plain convs) */
+  UH_EPI_CONVT = 3        /* N = 4*Cout, n = tap*Cout+co: out[(b,2y+tap/2,2x+tap%2)][co] = acc + bias[co];
+                             out has geometry (B,2H,2W); pad rows of out are written as zero */
+};
+int uh_conv_gemm(int B, int H, int W,
+                 const void* a, int a_cstride, int a_coff, int K,
+                 const void* w_packed, int N, int T, int mode,
+                 void* out, int o_cstride, int o_coff,
+                 const float* bias, const float* scale, const float* shift,
+                 float* stat_partial, const uint8_t* rowmask, uh_stream s);
+/* number of M tiles (= rows of stat_partial) uh_conv_gemm uses for this problem */
+int uh_conv_gemm_mtiles(int B, int H, int W, int N);
+
+/* ---- weight gradient (MFMA bf16, fp32 accumulate, split over pixels) --------------------
+ * partial[s][n][t][k] = sum_{m in split s} dy[m][n] * a[m + off(t)][k]; then
+ * grad[n*sn + t*st + k*sk] = sum_s partial[s][n*on + t*ot + k].
+ * Replaces the weight-gradient half of convolution_backward for every conv above. */
+int uh_conv_wgrad_splits(int B, int H, int W, int N, int K, int T);
+size_t uh_conv_wgrad_workspace(int B, int H, int W, int N, int K, int T);
+int uh_conv_wgrad(int B, int H, int W,
+                  const void* dy, int dy_cstride, int dy_coff, int N,
+                  const void* a, int a_cstride, int a_coff, int K, int T,
+                  float* partial, uh_stream s);
+int uh_wgrad_reduce(const float* partial, int S, int N, int T, int K,
+                    long long on, long long ot, long long sn, long long st, long long sk,
+                    float* grad, int accumulate, uh_stream s);
+
+/* ---- first layer: Conv2d(Cin<=4 -> Cout, 3x3, pad 1) on NCHW fp32 input (unet.py:99) ------ */
+int uh_conv_first_fwd(int B, int H, int W, int Cin, int Cout,
+                      const float* x_nchw, const float* w_oihw, const float* bias,
+                      int mode, const float* scale, const float* shift,
+                      void* out, int o_cstride, int o_coff, float* stat_partial, uh_stream s);
+int uh_conv_first_parts(int B, int H, int W);
+int uh_conv_first_wgrad(int B, int H, int W, int Cin, int Cout,
+                        const float* x_nchw, const void* dy, int dy_cstride, int dy_coff,
+                        float* partial, uh_stream s);     /* partial[parts][Cout][Cin*9] */
+int uh_conv_first_wgrad_parts(int B, int H, int W);
+
+/* ---- BatchNorm2d (train) + ReLU (unet.py:99-169, defaults eps 1e-5 momentum 0.1) --------- */
+/* stats: partial[P][2][C] -> mean, invstd, scale = gamma*invstd, shift = beta - mean*scale;
+ * running_mean/var (unbiased var) and num_batches_tracked updated in place when non-null. */
+int uh_bn_finalize(const float* partial, int P, int C, long long count,
+                   const float* gamma, const float* beta, float eps, float momentum,
+                   float* mean, float* invstd, float* scale, float* shift,
+                   float* running_mean, float* running_var, long long* num_batches_tracked, uh_stream s);
+/* eval mode: scale = gamma/sqrt(rv+eps); shift = beta + (conv_bias - rm)*scale */
+int uh_bn_fold_eval(int C, const float* gamma, const float* beta, const float* rm, const float* rv,
+                    const float* conv_bias, float eps, float* scale, float* shift, uh_stream s);
+/* a = relu(y*scale + shift) on interior rows, 0 on pads */
+int uh_bn_relu_apply(long long Mp, int C, const void* y, int y_cstride, int y_coff,
+                     const float* scale, const float* shift, const uint8_t* rowmask,
+                     void* a, int a_cstride, int a_coff, uh_stream s);
+/* backward of relu(bn(y)):  dyh = da * (y*scale+shift > 0); partial[P][2][C] = (sum dyh, sum dyh*xhat) */
+int uh_bn_bwd_parts(long long Mp, int C);
+int uh_bn_relu_bwd_reduce(long long Mp, int C, const void* da, int da_cstride, int da_coff,
+                          const void* y, int y_cstride, int y_coff,
+                          const float* mean, const float* invstd, const float* scale, const float* shift,
+                          float* partial, uh_stream s);
+/* dgamma = sum dyh*xhat, dbeta = sum dyh, coef[0][c] = dbeta/count, coef[1][c] = dgamma/count */
+int uh_bn_bwd_finalize(const float* partial, int P, int C, long long count,
+                       float* dgamma, float* dbeta, float* coef, int accumulate, uh_stream s);
+/* dy = scale * (dyh - coef0 - xhat*coef1) on interior rows, 0 on pads */
+int uh_bn_relu_bwd_apply(long long Mp, int C, const void* da, int da_cstride, int da_coff,
+                         const void* y, int y_cstride, int y_coff,
+                         const float* mean, const float* invstd, const float* scale, const float* shift,
+                         const float* coef, const uint8_t* rowmask,
+                         void* dy, int dy_cstride, int dy_coff, uh_stream s);
+
+/* ---- MaxPool2d(2,2) (unet.py:103-124) ---------------------------------------------------- */
+int uh_maxpool2_fwd(int B, int H, int W, int C, const void* a, int a_cstride, int a_coff,
+                    void* out, int o_cstride, int o_coff, uh_stream s);
+/* da[m] = (dp routed to the FIRST maximum of the window, row-major order) + (add ? add[m] : 0) */
+int uh_maxpool2_bwd(int B, int H, int W, int C, const void* a, int a_cstride, int a_coff,
+                    const void* dp, int dp_cstride, int dp_coff,
+                    const void* add, int add_cstride, int add_coff,
+                    void* da, int da_cstride, int da_coff, uh_stream s);
+
+/* ---- space-to-depth 2x2: out[(b,y,x)][t*C + c] = in[(b,2y+t/2,2x+t%2)][c]; in geometry (B,2H,2W) ----
+ * Turns the gradient of a k2 s2 transposed conv, and the input of a k2 s2 conv (lunext.py:139-154),
+ * into a T=1 GEMM operand. */
+int uh_space_to_depth2(int B, int H, int W, int C, const void* in, int i_cstride, int i_coff,
+                       void* out, int o_cstride, int o_coff, uh_stream s);
+/* inverse scatter: out[(b,2y+t/2,2x+t%2)][c] = in[(b,y,x)][t*C + c], pads of out zero */
+int uh_depth_to_space2(int B, int H, int W, int C, const void* in, int i_cstride, int i_coff,
+                       void* out, int o_cstride, int o_coff, uh_stream s);
+
+/* ---- per-channel sum over rows: partial-free two-pass (bias gradients) ---------------------- */
+int uh_colsum_parts(long long Mp, int C);
+int uh_colsum(long long Mp, int C, const void* x, int cstride, int coff, float* partial, uh_stream s);
+int uh_colsum_finalize(const float* partial, int P, int C, int fold, float* out, int accumulate, uh_stream s);
+
+/* ---- 1x1 segmentation head Conv2d(C -> OC) (unet.py:173; lunext.py:257), fp32 NCHW logits ------ */
+int uh_head_fwd(int B, int H, int W, int C, int OC, const void* a, int a_cstride, int a_coff,
+                const float* w, const float* bias, float* logits_nchw, uh_stream s);
+int uh_head_bwd_parts(int B, int H, int W);
+int uh_head_bwd(int B, int H, int W, int C, int OC, const void* a, int a_cstride, int a_coff,
+                const float* w, const float* dlogits_nchw,
+                void* da, int da_cstride, int da_coff, float* partial /*[P][OC][C+1]*/, uh_stream s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

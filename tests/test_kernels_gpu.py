@@ -1,0 +1,397 @@
+"""Per-kernel parity: every C-ABI entry point of libunet_hip.so against the same operation done
+with plain PyTorch fp32 ops on the CPU (the ATen calls the reference's modules dispatch).
+Inputs are rounded to bf16 first, so the only differences left are fp32 summation order and the
+final bf16 rounding of stored activations; tolerances below are stated per test."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip("needs a GPU", allow_module_level=True)
+
+from unet_amd import _lib                    # noqa: E402
+from unet_amd._lib import call, lib          # noqa: E402
+from unet_amd.layout import new_act, pool_for, mp_rows   # noqa: E402
+
+DEV = torch.device("cuda", 0)
+
+
+def S():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def bf(t):
+    return t.to(torch.bfloat16).float()
+
+
+def act_from(t, cstride=None, coff=0):
+    B, C, H, W = t.shape
+    a = new_act(B, H, W, cstride or C, DEV, cstride=cstride or C).window(coff, C)
+    a.fill_from_nchw(t.to(DEV))
+    return a
+
+
+def rowmask(B, H, W):
+    return pool_for(DEV).rowmask(B, H, W)
+
+
+def close(got, want, rel, what=""):
+    got, want = got.detach().float().cpu(), want.detach().float().cpu()
+    err = (got - want).abs().max().item()
+    ref = want.abs().max().item()
+    assert err <= rel * ref + 1e-6, f"{what}: max err {err:.4g} vs ref max {ref:.4g} (rel tol {rel})"
+
+
+def pads_are_zero(a):
+    B, H, W = a.B, a.H, a.W
+    rows = a.padded_rows().float().view(B, H + 1, W + 1, a.C)
+    assert rows[:, H, :, :].abs().max().item() == 0
+    assert rows[:, :, W, :].abs().max().item() == 0
+    g = a.guard
+    assert a.buf[:g].abs().max().item() == 0 and a.buf[g + a.Mp:].abs().max().item() == 0, "guard rows were written"
+
+
+def pack_conv(w):          # OIHW -> [co][t][ci] bf16
+    co, ci = w.shape[:2]
+    dst = torch.empty(co * 9 * ci, dtype=torch.bfloat16, device=DEV)
+    call("uh_pack_weights", w.data_ptr(), dst.data_ptr(), co, 9, ci, ci * 9, 1, 9, 9 * ci, ci, 0, S())
+    return dst
+
+
+CONV_SHAPES = [  # B, H, W, Cin, Cout
+    (2, 16, 16, 64, 64),       # 256x64 tile config
+    (1, 8, 24, 128, 128),      # 128x128 tile config, non-square
+    (3, 4, 4, 64, 192),        # N not a multiple of 128, tiny image (tiles span several images)
+    (1, 32, 32, 192, 128),     # three K chunks
+    (2, 2, 2, 128, 256),       # deepest-level shape of a 32x32 input
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", CONV_SHAPES)
+def test_conv_gemm_raw_stats(B, H, W, Cin, Cout):
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + Cin)
+    x = bf(torch.randn(B, Cin, H, W, generator=g))
+    w = bf(torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5))
+    b = torch.randn(Cout, generator=g)
+    a = act_from(x)
+    out = new_act(B, H, W, Cout, DEV)
+    wd = w.to(DEV)
+    parts = lib.uh_conv_gemm_mtiles(B, H, W, Cout)
+    stat = torch.zeros(parts, 2, Cout, device=DEV)
+    bd = b.to(DEV)
+    call("uh_conv_gemm", B, H, W, a.ptr, a.cstride, a.coff, Cin, pack_conv(wd).data_ptr(), Cout, 9, _lib.EPI_RAW_STATS,
+         out.ptr, out.cstride, out.coff, bd.data_ptr(), None, None, stat.data_ptr(), rowmask(B, H, W).data_ptr(), S())
+    torch.cuda.synchronize()
+    want = F.conv2d(x, w, b, padding=1)
+    close(out.to_nchw(), want, 1e-2, "conv output (bf16 store: 2^-8 relative)")
+    pads_are_zero(out)
+    s = stat.sum(0).cpu()
+    close(s[0], want.sum((0, 2, 3)), 2e-3, "sum y")
+    close(s[1], (want * want).sum((0, 2, 3)), 2e-3, "sum y^2")
+
+
+def test_conv_gemm_affine_relu_and_views():
+    """eval-mode epilogue, reading from and writing into channel windows of wider buffers."""
+    B, H, W, Cin, Cout = 2, 8, 8, 64, 128
+    g = torch.Generator().manual_seed(5)
+    x = bf(torch.randn(B, Cin, H, W, generator=g))
+    w = bf(torch.randn(Cout, Cin, 3, 3, generator=g) / 24)
+    scale, shift = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    a = act_from(x, cstride=192, coff=64)
+    out = new_act(B, H, W, 256, DEV, cstride=256).window(128, Cout)
+    wd, sc, sh = w.to(DEV), scale.to(DEV), shift.to(DEV)
+    call("uh_conv_gemm", B, H, W, a.ptr, a.cstride, a.coff, Cin, pack_conv(wd).data_ptr(), Cout, 9,
+         _lib.EPI_AFFINE_RELU, out.ptr, out.cstride, out.coff, None, sc.data_ptr(), sh.data_ptr(), None,
+         rowmask(B, H, W).data_ptr(), S())
+    torch.cuda.synchronize()
+    want = F.relu(F.conv2d(x, w, None, padding=1) * scale[None, :, None, None] + shift[None, :, None, None])
+    close(out.to_nchw(), want, 1e-2, "affine+relu")
+    pads_are_zero(out)
+    assert out.buf[:, :128].abs().max().item() == 0, "wrote outside its channel window"
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 16, 16, 64, 64), (1, 8, 8, 128, 64), (2, 4, 8, 64, 128)])
+def test_conv_dgrad(B, H, W, Cin, Cout):
+    g = torch.Generator().manual_seed(17)
+    dy = bf(torch.randn(B, Cout, H, W, generator=g))
+    w = bf(torch.randn(Cout, Cin, 3, 3, generator=g) / 24)
+    wd = w.to(DEV)
+    pk = torch.empty(Cin * 9 * Cout, dtype=torch.bfloat16, device=DEV)
+    call("uh_pack_weights", wd.data_ptr(), pk.data_ptr(), Cin, 9, Cout, 9, 1, Cin * 9, 9 * Cout, Cout, 1, S())
+    a = act_from(dy)
+    out = new_act(B, H, W, Cin, DEV)
+    call("uh_conv_gemm", B, H, W, a.ptr, a.cstride, a.coff, Cout, pk.data_ptr(), Cin, 9, _lib.EPI_MASKED,
+         out.ptr, out.cstride, out.coff, None, None, None, None, rowmask(B, H, W).data_ptr(), S())
+    torch.cuda.synchronize()
+    want = F.conv_transpose2d(dy, w, padding=1)          # = input gradient of conv2d(pad=1)
+    close(out.to_nchw(), want, 1e-2, "dgrad")
+    pads_are_zero(out)
+
+
+@pytest.mark.parametrize("B,h,w,Cin,Cout", [(2, 4, 4, 128, 64), (1, 2, 6, 64, 64), (2, 8, 8, 256, 128)])
+def test_conv_transpose_fwd(B, h, w, Cin, Cout):
+    g = torch.Generator().manual_seed(23)
+    x = bf(torch.randn(B, Cin, h, w, generator=g))
+    wt = bf(torch.randn(Cin, Cout, 2, 2, generator=g) / Cin ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    wd, bd = wt.to(DEV), b.to(DEV)
+    pk = torch.empty(4 * Cout * Cin, dtype=torch.bfloat16, device=DEV)
+    call("uh_pack_weights", wd.data_ptr(), pk.data_ptr(), Cout, 4, Cin, 4, 1, Cout * 4, Cin, Cout * Cin, 0, S())
+    a = act_from(x)
+    cat = new_act(B, 2 * h, 2 * w, 2 * Cout, DEV, cstride=2 * Cout)
+    cat.buf.fill_(7.0)                                  # poison: every row of the window must be written
+    out = cat.window(Cout, Cout)
+    call("uh_conv_gemm", B, h, w, a.ptr, a.cstride, a.coff, Cin, pk.data_ptr(), 4 * Cout, 1, _lib.EPI_CONVT,
+         out.ptr, out.cstride, out.coff, bd.data_ptr(), None, None, None, rowmask(B, h, w).data_ptr(), S())
+    torch.cuda.synchronize()
+    want = F.conv_transpose2d(x, wt, b, stride=2)
+    close(out.to_nchw(), want, 1e-2, "convT")
+    rows = out.padded_rows().float().view(B, 2 * h + 1, 2 * w + 1, Cout)
+    assert rows[:, 2 * h].abs().max().item() == 0 and rows[:, :, 2 * w].abs().max().item() == 0
+    assert (cat.window(0, Cout).padded_rows().float() == 7.0).all(), "wrote outside its channel window"
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 16, 16, 64, 64), (1, 8, 24, 128, 64), (3, 4, 4, 64, 128),
+                                            (2, 2, 2, 128, 128), (1, 40, 40, 64, 64)])
+def test_conv_wgrad(B, H, W, Cin, Cout):
+    g = torch.Generator().manual_seed(31)
+    x = bf(torch.randn(B, Cin, H, W, generator=g))
+    dy = bf(torch.randn(B, Cout, H, W, generator=g))
+    a, d = act_from(x), act_from(dy)
+    Sp = lib.uh_conv_wgrad_splits(B, H, W, Cout, Cin, 9)
+    assert lib.uh_conv_wgrad_workspace(B, H, W, Cout, Cin, 9) == Sp * Cout * 9 * Cin * 4
+    part = torch.empty(Sp * Cout * 9 * Cin, device=DEV)
+    call("uh_conv_wgrad", B, H, W, d.ptr, d.cstride, d.coff, Cout, a.ptr, a.cstride, a.coff, Cin, 9, part.data_ptr(), S())
+    dw = torch.empty(Cout, Cin, 3, 3, device=DEV)
+    call("uh_wgrad_reduce", part.data_ptr(), Sp, Cout, 9, Cin, 9 * Cin, Cin, Cin * 9, 1, 9, dw.data_ptr(), 0, S())
+    torch.cuda.synchronize()
+    want = torch.nn.grad.conv2d_weight(x, (Cout, Cin, 3, 3), dy, padding=1)
+    close(dw, want, 2e-3, "wgrad (fp32 accumulate of bf16 products)")
+
+
+def test_conv_wgrad_1x1_and_transposed():
+    """T=1 weight gradient as used for the transposed conv: space-to-depth then GEMM."""
+    B, h, w, Cin, Cout = 2, 4, 6, 128, 64
+    g = torch.Generator().manual_seed(37)
+    x = bf(torch.randn(B, Cin, h, w, generator=g))
+    dy = bf(torch.randn(B, Cout, 2 * h, 2 * w, generator=g))
+    wt = bf(torch.randn(Cin, Cout, 2, 2, generator=g) / 8)
+    a, d = act_from(x), act_from(dy, cstride=2 * Cout, coff=Cout)
+    d4 = new_act(B, h, w, 4 * Cout, DEV)
+    call("uh_space_to_depth2", B, h, w, Cout, d.ptr, d.cstride, d.coff, d4.ptr, d4.cstride, d4.coff, S())
+    Sp = lib.uh_conv_wgrad_splits(B, h, w, 4 * Cout, Cin, 1)
+    part = torch.empty(Sp * 4 * Cout * Cin, device=DEV)
+    call("uh_conv_wgrad", B, h, w, d4.ptr, d4.cstride, d4.coff, 4 * Cout, a.ptr, a.cstride, a.coff, Cin, 1,
+         part.data_ptr(), S())
+    dw = torch.empty(Cin, Cout, 2, 2, device=DEV)
+    call("uh_wgrad_reduce", part.data_ptr(), Sp, Cout, 4, Cin, Cin, Cout * Cin, 4, 1, Cout * 4, dw.data_ptr(), 0, S())
+    # input gradient through the same d4
+    wd = wt.to(DEV)
+    pk = torch.empty(Cin * 4 * Cout, dtype=torch.bfloat16, device=DEV)
+    call("uh_pack_weights", wd.data_ptr(), pk.data_ptr(), Cin, 4, Cout, Cout * 4, 1, 4, 4 * Cout, Cout, 0, S())
+    dx = new_act(B, h, w, Cin, DEV)
+    call("uh_conv_gemm", B, h, w, d4.ptr, d4.cstride, d4.coff, 4 * Cout, pk.data_ptr(), Cin, 1, _lib.EPI_MASKED,
+         dx.ptr, dx.cstride, dx.coff, None, None, None, None, rowmask(B, h, w).data_ptr(), S())
+    torch.cuda.synchronize()
+    xr = x.clone().requires_grad_(True)
+    wr = wt.clone().requires_grad_(True)
+    F.conv_transpose2d(xr, wr, None, stride=2).backward(dy)
+    close(dw, wr.grad, 2e-3, "convT wgrad")
+    close(dx.to_nchw(), xr.grad, 1e-2, "convT dgrad")
+    pads_are_zero(dx)
+    pads_are_zero(d4)
+    # depth_to_space is the inverse scatter
+    back = new_act(B, 2 * h, 2 * w, Cout, DEV)
+    back.buf.fill_(3.0)
+    back.buf[:back.guard] = 0
+    back.buf[back.guard + back.Mp:] = 0
+    call("uh_depth_to_space2", B, h, w, Cout, d4.ptr, d4.cstride, d4.coff, back.ptr, back.cstride, back.coff, S())
+    torch.cuda.synchronize()
+    close(back.to_nchw(), dy, 0.0, "depth_to_space(space_to_depth(x)) == x")
+    pads_are_zero(back)
+
+
+@pytest.mark.parametrize("Cin", [1, 2, 3, 4])
+def test_conv_first(Cin):
+    B, H, W, Cout = 2, 16, 24, 64
+    g = torch.Generator().manual_seed(41 + Cin)
+    x = torch.rand(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / 5
+    b = torch.randn(Cout, generator=g)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    out = new_act(B, H, W, Cout, DEV)
+    parts = lib.uh_conv_first_parts(B, H, W)
+    stat = torch.zeros(parts, 2, Cout, device=DEV)
+    call("uh_conv_first_fwd", B, H, W, Cin, Cout, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), _lib.EPI_RAW_STATS,
+         None, None, out.ptr, out.cstride, out.coff, stat.data_ptr(), S())
+    torch.cuda.synchronize()
+    want = F.conv2d(x, w, b, padding=1)
+    close(out.to_nchw(), want, 6e-3, "first conv")
+    pads_are_zero(out)
+    s = stat.sum(0).cpu()
+    close(s[0], want.sum((0, 2, 3)), 1e-4, "sum y (fp32 path)")
+    close(s[1], (want * want).sum((0, 2, 3)), 1e-4, "sum y^2")
+    # eval epilogue
+    scale, shift = (torch.rand(Cout, generator=g) + 0.5), torch.randn(Cout, generator=g)
+    sc, sh = scale.to(DEV), shift.to(DEV)
+    call("uh_conv_first_fwd", B, H, W, Cin, Cout, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), _lib.EPI_AFFINE_RELU,
+         sc.data_ptr(), sh.data_ptr(), out.ptr, out.cstride, out.coff, None, S())
+    torch.cuda.synchronize()
+    want2 = F.relu(F.conv2d(x, w, None, padding=1) * scale[None, :, None, None] + shift[None, :, None, None])
+    close(out.to_nchw(), want2, 6e-3, "first conv eval")
+    # weight gradient
+    dy = bf(torch.randn(B, Cout, H, W, generator=g))
+    d = act_from(dy)
+    wparts = lib.uh_conv_first_wgrad_parts(B, H, W)
+    part = torch.empty(wparts * Cout * Cin * 9, device=DEV)
+    call("uh_conv_first_wgrad", B, H, W, Cin, Cout, xd.data_ptr(), d.ptr, d.cstride, d.coff, part.data_ptr(), S())
+    dw = torch.empty(Cout, Cin, 3, 3, device=DEV)
+    call("uh_wgrad_reduce", part.data_ptr(), wparts, Cout, 1, Cin * 9, Cin * 9, 0, Cin * 9, 0, 1, dw.data_ptr(), 0, S())
+    torch.cuda.synchronize()
+    close(dw, torch.nn.grad.conv2d_weight(x, (Cout, Cin, 3, 3), dy, padding=1), 1e-4, "first conv wgrad")
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 16, 16, 64), (3, 4, 6, 256), (1, 8, 8, 1024)])
+def test_batchnorm_relu_forward_backward(B, H, W, C):
+    g = torch.Generator().manual_seed(43)
+    y = bf(torch.randn(B, C, H, W, generator=g) * 2 + 0.5)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    rm0, rv0 = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    # statistics come from the conv epilogue; emulate a two-row partial here
+    ys = y.double()
+    part = torch.zeros(2, 2, C, dtype=torch.float32)
+    part[0, 0] = ys[:1].sum((0, 2, 3)).float() if B > 1 else ys.sum((0, 2, 3)).float()
+    part[0, 1] = (ys[:1] ** 2).sum((0, 2, 3)).float() if B > 1 else (ys ** 2).sum((0, 2, 3)).float()
+    if B > 1:
+        part[1, 0] = ys[1:].sum((0, 2, 3)).float()
+        part[1, 1] = (ys[1:] ** 2).sum((0, 2, 3)).float()
+    pd = part.to(DEV)
+    gd, bd, rm, rv = gamma.to(DEV), beta.to(DEV), rm0.to(DEV), rv0.to(DEV)
+    nbt = torch.tensor(5, dtype=torch.int64, device=DEV)
+    st = torch.empty(4, C, device=DEV)
+    call("uh_bn_finalize", pd.data_ptr(), 2, C, B * H * W, gd.data_ptr(), bd.data_ptr(), 1e-5, 0.1, st[0].data_ptr(),
+         st[1].data_ptr(), st[2].data_ptr(), st[3].data_ptr(), rm.data_ptr(), rv.data_ptr(), nbt.data_ptr(), S())
+    ya = act_from(y)
+    a = new_act(B, H, W, C, DEV)
+    mask = rowmask(B, H, W)
+    call("uh_bn_relu_apply", ya.Mp, C, ya.ptr, ya.cstride, ya.coff, st[2].data_ptr(), st[3].data_ptr(), mask.data_ptr(),
+         a.ptr, a.cstride, a.coff, S())
+    torch.cuda.synchronize()
+    bn = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(gamma); bn.bias.copy_(beta); bn.running_mean.copy_(rm0); bn.running_var.copy_(rv0)
+        bn.num_batches_tracked.fill_(5)
+    yr = y.clone().requires_grad_(True)
+    ar = F.relu(bn(yr))
+    close(a.to_nchw(), ar, 1e-2, "bn+relu")
+    pads_are_zero(a)
+    close(rm, bn.running_mean, 1e-5, "running_mean")
+    close(rv, bn.running_var, 1e-5, "running_var")
+    assert nbt.item() == 6
+    # backward
+    da = bf(torch.randn(B, C, H, W, generator=g))
+    ar.backward(da)
+    dact = act_from(da)
+    parts = lib.uh_bn_bwd_parts(ya.Mp, C)
+    bp = torch.empty(parts, 2, C, device=DEV)
+    call("uh_bn_relu_bwd_reduce", ya.Mp, C, dact.ptr, dact.cstride, dact.coff, ya.ptr, ya.cstride, ya.coff,
+         st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(), st[3].data_ptr(), bp.data_ptr(), S())
+    dg, db, coef = torch.empty(C, device=DEV), torch.empty(C, device=DEV), torch.empty(2, C, device=DEV)
+    call("uh_bn_bwd_finalize", bp.data_ptr(), parts, C, B * H * W, dg.data_ptr(), db.data_ptr(), coef.data_ptr(), 0, S())
+    dy = new_act(B, H, W, C, DEV)
+    call("uh_bn_relu_bwd_apply", ya.Mp, C, dact.ptr, dact.cstride, dact.coff, ya.ptr, ya.cstride, ya.coff,
+         st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(), st[3].data_ptr(), coef.data_ptr(), mask.data_ptr(),
+         dy.ptr, dy.cstride, dy.coff, S())
+    torch.cuda.synchronize()
+    close(dg, bn.weight.grad, 1e-4, "dgamma")
+    close(db, bn.bias.grad, 1e-4, "dbeta")
+    close(dy.to_nchw(), yr.grad, 1e-2, "dy")
+    pads_are_zero(dy)
+    # eval fold
+    cb = torch.randn(C, generator=g).to(DEV)
+    fs = torch.empty(2, C, device=DEV)
+    call("uh_bn_fold_eval", C, gd.data_ptr(), bd.data_ptr(), rm.data_ptr(), rv.data_ptr(), cb.data_ptr(), 1e-5,
+         fs[0].data_ptr(), fs[1].data_ptr(), S())
+    torch.cuda.synchronize()
+    sc = gamma / torch.sqrt(rv.cpu() + 1e-5)
+    close(fs[0], sc, 1e-6, "fold scale")
+    close(fs[1], beta + (cb.cpu() - rm.cpu()) * sc, 1e-5, "fold shift")
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 8, 8, 64), (1, 4, 12, 128), (3, 2, 2, 512)])
+def test_maxpool(B, H, W, C):
+    g = torch.Generator().manual_seed(47)
+    # coarse values so that windows contain exact ties: the FIRST maximum (row-major) takes the gradient
+    x = (torch.randint(0, 4, (B, C, H, W), generator=g).float() / 2)
+    a = act_from(x, cstride=2 * C, coff=0)
+    p = new_act(B, H // 2, W // 2, C, DEV)
+    call("uh_maxpool2_fwd", B, H, W, C, a.ptr, a.cstride, a.coff, p.ptr, p.cstride, p.coff, S())
+    xr = x.clone().requires_grad_(True)
+    pr = F.max_pool2d(xr, 2, 2)
+    torch.cuda.synchronize()
+    close(p.to_nchw(), pr, 0.0, "maxpool")
+    pads_are_zero(p)
+    dp = bf(torch.randn(B, C, H // 2, W // 2, generator=g))
+    add = bf(torch.randn(B, C, H, W, generator=g))
+    pr.backward(dp)
+    dpa, adda = act_from(dp), act_from(add, cstride=2 * C, coff=0)
+    da = new_act(B, H, W, C, DEV)
+    da.buf[da.guard:da.guard + da.Mp] = 9.0
+    call("uh_maxpool2_bwd", B, H, W, C, a.ptr, a.cstride, a.coff, dpa.ptr, dpa.cstride, dpa.coff, adda.ptr,
+         adda.cstride, adda.coff, da.ptr, da.cstride, da.coff, S())
+    torch.cuda.synchronize()
+    close(da.to_nchw(), bf(xr.grad + add), 4e-3, "maxpool bwd + skip add")
+    pads_are_zero(da)
+
+
+def test_colsum_and_head():
+    B, H, W, C = 2, 8, 12, 64
+    g = torch.Generator().manual_seed(53)
+    x = bf(torch.randn(B, C, H, W, generator=g))
+    a = act_from(x, cstride=128, coff=64)
+    parts = lib.uh_colsum_parts(a.Mp, C)
+    cp = torch.empty(parts, C, device=DEV)
+    call("uh_colsum", a.Mp, C, a.ptr, a.cstride, a.coff, cp.data_ptr(), S())
+    out = torch.empty(C, device=DEV)
+    call("uh_colsum_finalize", cp.data_ptr(), parts, C, 1, out.data_ptr(), 0, S())
+    torch.cuda.synchronize()
+    close(out, x.sum((0, 2, 3)), 1e-5, "colsum")
+    for OC in (1, 2):
+        w = torch.randn(OC, C, generator=g) / 8
+        b = torch.randn(OC, generator=g)
+        wd, bd = w.to(DEV), b.to(DEV)
+        logits = torch.empty(B, OC, H, W, device=DEV)
+        call("uh_head_fwd", B, H, W, C, OC, a.ptr, a.cstride, a.coff, wd.data_ptr(), bd.data_ptr(), logits.data_ptr(), S())
+        torch.cuda.synchronize()
+        xr = x.clone().requires_grad_(True)
+        wr = w.clone().requires_grad_(True)
+        br = b.clone().requires_grad_(True)
+        lr = F.conv2d(xr, wr.view(OC, C, 1, 1), br)
+        close(logits, lr, 1e-5, "head fwd (fp32 out)")
+        dl = torch.randn(B, OC, H, W, generator=g)
+        lr.backward(dl)
+        dld = dl.to(DEV)
+        da = new_act(B, H, W, C, DEV)
+        hp_parts = lib.uh_head_bwd_parts(B, H, W)
+        hp = torch.empty(hp_parts, OC, C + 1, device=DEV)
+        call("uh_head_bwd", B, H, W, C, OC, a.ptr, a.cstride, a.coff, wd.data_ptr(), dld.data_ptr(), da.ptr, da.cstride,
+             da.coff, hp.data_ptr(), S())
+        hw = torch.empty(OC * (C + 1), device=DEV)
+        call("uh_colsum_finalize", hp.data_ptr(), hp_parts, OC * (C + 1), 1, hw.data_ptr(), 0, S())
+        torch.cuda.synchronize()
+        hw = hw.view(OC, C + 1).cpu()
+        close(hw[:, :C], wr.grad, 1e-4, "head dW")
+        close(hw[:, C], br.grad, 1e-4, "head db")
+        close(da.to_nchw(), xr.grad, 1e-2, "head dX")
+        pads_are_zero(da)
+
+
+def test_bad_arguments_are_reported():
+    a = new_act(1, 4, 4, 64, DEV)
+    with pytest.raises(_lib.HipKernelError, match="multiple of 64"):
+        call("uh_conv_gemm", 1, 4, 4, a.ptr, 64, 0, 48, a.ptr, 64, 9, 0, a.ptr, 64, 0, None, None, None, a.ptr,
+             a.ptr, S())
+    with pytest.raises(_lib.HipKernelError, match="even"):
+        call("uh_maxpool2_fwd", 1, 3, 4, 64, a.ptr, 64, 0, a.ptr, 64, 0, S())

@@ -1,0 +1,229 @@
+"""End-to-end parity of the HIP U-Net (unet_amd.UNet) with the reference.
+
+Two anchors: (1) the golden fixtures captured from the reference import
+(tests/golden/make_golden.py) and (2) the CPU oracle (oracle/ref_cpu.py, itself pinned to those
+fixtures) on fresh seeded inputs.  The HIP path stores activations and activation gradients in
+bf16 (8 significant bits) through 23 stacked convolutions, with fp32 accumulation, fp32
+BatchNorm statistics and fp32 parameter gradients; the stated tolerances are for that."""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip("needs a GPU", allow_module_level=True)
+
+import unet_amd                              # noqa: E402
+from oracle import ref_cpu                   # noqa: E402
+
+DEV = torch.device("cuda", 0)
+
+# tolerances (bf16 activations, fp32 accumulate)
+LOGIT_REL = 3e-2        # max |logit error| relative to max |logit|
+LOSS_REL = 5e-3         # BCE loss
+GRAD_COS = 0.99         # cosine similarity per parameter tensor (tensors with a non-trivial gradient)
+GRAD_NORM = 0.05        # relative error of the gradient norm per tensor
+
+
+def cosine(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return (a @ b / (a.norm() * b.norm() + 1e-30)).item()
+
+
+def compare_grads(model, ref_grads, min_norm_frac=1e-3):
+    """ref_grads: name -> tensor.  Tensors whose reference gradient is pure rounding noise
+    (conv biases under train-mode BatchNorm: analytically zero) are checked for smallness only."""
+    total = max(g.norm().item() for g in ref_grads.values())
+    worst_cos, worst_norm = 1.0, 0.0
+    for n, p in model.named_parameters():
+        if n not in ref_grads:
+            continue
+        ref = ref_grads[n]
+        got = p.grad.detach().float().cpu()
+        assert got.shape == ref.shape, n
+        assert torch.isfinite(got).all(), n
+        if n.endswith(".bias") and n.startswith("conv") and not n.startswith("conv_final"):
+            # bias of a conv in front of BatchNorm: exactly zero in exact arithmetic
+            assert got.abs().max().item() <= 1e-3 * total, n
+            continue
+        if ref.norm().item() < min_norm_frac * total:
+            continue
+        c = cosine(got, ref)
+        r = abs(got.norm().item() / ref.norm().item() - 1.0)
+        worst_cos, worst_norm = min(worst_cos, c), max(worst_norm, r)
+        assert c >= GRAD_COS, f"{n}: cosine {c:.4f}"
+        assert r <= GRAD_NORM, f"{n}: norm ratio error {r:.4f}"
+    return worst_cos, worst_norm
+
+
+def test_unet_golden_small(golden_dir):
+    fx = np.load(os.path.join(golden_dir, "unet_s0_b2_32.npz"), allow_pickle=False)
+    torch.manual_seed(0)
+    model = unet_amd.create_unet(3, 1)
+    cs = np.array([[p.detach().double().sum().item(), p.detach().double().abs().sum().item()]
+                   for p in model.parameters()])
+    np.testing.assert_array_equal(cs, fx["param_checksums"])      # same init as the reference, bit for bit
+    model = model.to(DEV)
+    x, m = torch.from_numpy(fx["x"]).to(DEV), torch.from_numpy(fx["mask"]).to(DEV)
+    model.train()
+    logits = model(x)
+    assert logits.shape == (2, 1, 32, 32) and logits.dtype == torch.float32
+    loss = nn.BCEWithLogitsLoss()(logits, m)
+    loss.backward()
+    want = torch.from_numpy(fx["train_logits"])
+    err = (logits.detach().cpu() - want).abs().max().item()
+    print(f"train logits: max err {err:.4g} (max |ref| {want.abs().max().item():.4g}); "
+          f"loss {loss.item():.6f} vs {float(fx['train_loss']):.6f}")
+    assert err <= LOGIT_REL * want.abs().max().item()
+    assert abs(loss.item() - float(fx["train_loss"])) <= LOSS_REL * float(fx["train_loss"])
+    ref_grads = {k[5:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("grad/")}
+    wc, wn = compare_grads(model, ref_grads)
+    print(f"grads: worst cosine {wc:.5f}, worst norm error {wn:.4f}")
+    # gradient norms of every parameter against the reference summary
+    names = list(fx["param_names"])
+    gs = fx["grad_summary"]
+    tot = gs[:, 0].max()
+    for n, p in model.named_parameters():
+        i = names.index(n)
+        if gs[i, 0] > 1e-3 * tot:
+            assert abs(p.grad.norm().item() / gs[i, 0] - 1) <= GRAD_NORM, n
+    for bn in ("bn1_1", "bn5_2", "bn_up4_2"):
+        mod = getattr(model, bn)
+        np.testing.assert_allclose(mod.running_mean.cpu().numpy(), fx[f"{bn}.running_mean"], rtol=0, atol=2e-2)
+        np.testing.assert_allclose(mod.running_var.cpu().numpy(), fx[f"{bn}.running_var"], rtol=5e-2, atol=1e-3)
+        assert mod.num_batches_tracked.item() == 1
+    feats = model.intermediate_features
+    assert len(feats) == 15
+    assert [list(t.shape) for t in feats] == fx["feature_shapes"].tolist()
+    np.testing.assert_allclose([t.double().abs().sum().item() for t in feats], fx["feature_abs_sums"], rtol=2e-2)
+
+
+def test_unet_eval_matches_oracle():
+    """inference path (folded BatchNorm): fresh model with non-trivial running statistics."""
+    torch.manual_seed(1)
+    ref = ref_cpu.RefUNet(3, 1)
+    x, _ = ref_cpu.synth_batch(2, 3, 64, 48)
+    ref.train()
+    with torch.no_grad():
+        for _ in range(3):
+            ref(x + 0.1 * torch.randn_like(x))          # move the running statistics off their defaults
+    model = unet_amd.UNet(3, 1)
+    model.load_state_dict(ref.state_dict())               # checkpoints interchange with the reference layout
+    model = model.to(DEV).eval()
+    ref.eval()
+    with torch.no_grad():
+        want = ref(x)
+        got = model(x.to(DEV)).cpu()
+    err = (got - want).abs().max().item()
+    print(f"eval logits: max err {err:.4g} (max |ref| {want.abs().max().item():.4g})")
+    assert err <= LOGIT_REL * want.abs().max().item()
+    # batch-1 fp32 inference as in test_helper/utils.py:116-125
+    with torch.no_grad():
+        one = model(x[:1].to(DEV)).cpu()
+    assert (one - want[:1]).abs().max().item() <= LOGIT_REL * want.abs().max().item()
+
+
+@pytest.mark.parametrize("B,C,H,W", [(4, 3, 64, 64), (1, 2, 16, 48), (3, 3, 32, 80)])
+def test_unet_train_step_matches_oracle(B, C, H, W):
+    torch.manual_seed(2)
+    ref = ref_cpu.RefUNet(C, 1)
+    model = copy.deepcopy(unet_amd.UNet(C, 1))
+    model.load_state_dict(ref.state_dict())
+    model = model.to(DEV)
+    x, m = ref_cpu.synth_batch(B, C, H, W)
+    ref.train(); model.train()
+    lr = nn.BCEWithLogitsLoss()(ref(x), m)
+    lr.backward()
+    logits = model(x.to(DEV))
+    lg = nn.BCEWithLogitsLoss()(logits, m.to(DEV))
+    lg.backward()
+    with torch.no_grad():
+        want = ref(x) if False else None
+    ref_grads = {n: p.grad for n, p in ref.named_parameters()}
+    wc, wn = compare_grads(model, ref_grads)
+    print(f"[{B}x{C}x{H}x{W}] loss {lg.item():.6f} vs {lr.item():.6f}; worst cosine {wc:.5f}, worst norm err {wn:.4f}")
+    assert abs(lg.item() - lr.item()) <= LOSS_REL * lr.item()
+    for n, buf in ref.named_buffers():
+        got = dict(model.named_buffers())[n].cpu()
+        if n.endswith("num_batches_tracked"):
+            assert got.item() == buf.item()
+        elif n.endswith("running_mean"):
+            assert (got - buf).abs().max().item() <= 2e-2, n
+        else:
+            assert ((got - buf).abs() <= 5e-2 * buf.abs() + 1e-3).all(), n
+
+
+def test_unet_under_autocast_and_gradscaler():
+    """The trainer's AMP contract (training_utils.py:117,139-155): fp16 autocast + GradScaler."""
+    torch.manual_seed(3)
+    model = unet_amd.UNet(3, 1).to(DEV)
+    x, m = ref_cpu.synth_batch(2, 3, 32, 32)
+    x, m = x.to(DEV), m.to(DEV)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    scaler = torch.amp.GradScaler("cuda")
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        with torch.amp.autocast("cuda"):
+            out = model(x)
+            loss = nn.BCEWithLogitsLoss()(out, m)
+        assert out.dtype == torch.float32
+        scaler.scale(loss).backward()
+        scaler.step(opt)
+        scaler.update()
+        losses.append(loss.item())
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    assert all(p.grad is not None and p.grad.dtype == torch.float32 for p in model.parameters())
+
+
+def test_unet_adam_trajectory_golden(golden_dir):
+    """config 1: B=4, 3x128x128, BCE, three Adam steps (lr 1e-3) against the reference's losses."""
+    fx = np.load(os.path.join(golden_dir, "unet_s0_b4_128_adam.npz"), allow_pickle=False)
+    torch.manual_seed(0)
+    model = unet_amd.UNet(3, 1).to(DEV)
+    g = torch.Generator().manual_seed(int(fx["seed_inputs"]))
+    x = torch.rand(4, 3, 128, 128, generator=g).to(DEV)
+    m = (torch.rand(4, 1, 128, 128, generator=g) > 0.5).float().to(DEV)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    losses = []
+    for step in range(3):
+        opt.zero_grad()
+        logits = model(x)
+        if step == 0:
+            sl = logits[0, 0, :32, :32].detach().cpu().numpy()
+            assert np.abs(sl - fx["logits0_slice"]).max() <= LOGIT_REL * np.abs(fx["logits0_slice"]).max()
+        loss = nn.BCEWithLogitsLoss()(logits, m)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    print("adam losses", losses, "reference", fx["losses"].tolist())
+    np.testing.assert_allclose(losses, fx["losses"], rtol=2e-2)
+
+
+def test_module_surface():
+    model = unet_amd.create_unet(3, 1).to(DEV)
+    x = torch.rand(1, 3, 16, 16, device=DEV)
+    model.eval()
+    with torch.no_grad():
+        y1 = model(x)
+    clone = copy.deepcopy(model)                           # k_fold.py:139
+    with torch.no_grad():
+        y2 = clone(x)
+    assert torch.equal(y1, y2)
+    sd = model.state_dict()
+    assert len(sd) == 136
+    with pytest.raises(ValueError, match="divisible by 16"):
+        model(torch.rand(1, 3, 20, 16, device=DEV))
+    with pytest.raises(RuntimeError, match="HIP kernels only"):
+        model(torch.rand(1, 3, 16, 16))
+    # two forwards before one backward must not share buffers
+    model.train()
+    a = model(x)
+    b = model(x * 0.5)
+    (a.sum() + b.sum()).backward()
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters())

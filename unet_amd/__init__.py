@@ -1,0 +1,13 @@
+"""unet_amd: MI355X (gfx950) implementation of the SaviorDT/UNet training/inference hot path.
+
+Public surface (same names and call conventions as the reference):
+    UNet, LUNeXt                      models/unet.py, models/lunext.py
+    soft_dice_cldice, soft_dice       losses/cl_dice.py
+    create_unet, create_lunext, save_model   models/model_utils.py
+Everything executes in hand-written HIP kernels behind the C ABI of include/unet_hip.h.
+"""
+from ._lib import lib, LIB_PATH, HipKernelError          # noqa: F401  (fails loudly if the .so is missing)
+from .unet import UNet                                   # noqa: F401
+from .model_utils import create_unet, create_lunext, save_model   # noqa: F401
+
+__all__ = ["UNet", "create_unet", "create_lunext", "save_model", "lib", "LIB_PATH", "HipKernelError"]

@@ -1,0 +1,91 @@
+"""ctypes binding of libunet_hip.so (declared in include/unet_hip.h).
+
+The HIP library is the product path: importing this module fails loudly if the shared
+library has not been built (``make -C unet_amd/csrc``); there is no CPU or eager fallback.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libunet_hip.so")
+
+P = ctypes.c_void_p
+I = ctypes.c_int
+L = ctypes.c_longlong
+F = ctypes.c_float
+Z = ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/unet_hip.h one to one
+SIGNATURES = {
+    "uh_last_error": (ctypes.c_char_p, []),
+    "uh_version": (I, []),
+    "uh_guard_rows": (I, [I]),
+    "uh_rowmask_build": (I, [I, I, I, P, P]),
+    "uh_pack_weights": (I, [P, P, I, I, I, L, L, L, L, L, I, P]),
+    "uh_conv_gemm": (I, [I, I, I, P, I, I, I, P, I, I, I, P, I, I, P, P, P, P, P, P]),
+    "uh_conv_gemm_mtiles": (I, [I, I, I, I]),
+    "uh_conv_wgrad_splits": (I, [I, I, I, I, I, I]),
+    "uh_conv_wgrad_workspace": (Z, [I, I, I, I, I, I]),
+    "uh_conv_wgrad": (I, [I, I, I, P, I, I, I, P, I, I, I, I, P, P]),
+    "uh_wgrad_reduce": (I, [P, I, I, I, I, L, L, L, L, L, P, I, P]),
+    "uh_conv_first_fwd": (I, [I, I, I, I, I, P, P, P, I, P, P, P, I, I, P, P]),
+    "uh_conv_first_parts": (I, [I, I, I]),
+    "uh_conv_first_wgrad": (I, [I, I, I, I, I, P, P, I, I, P, P]),
+    "uh_conv_first_wgrad_parts": (I, [I, I, I]),
+    "uh_bn_finalize": (I, [P, I, I, L, P, P, F, F, P, P, P, P, P, P, P, P]),
+    "uh_bn_fold_eval": (I, [I, P, P, P, P, P, F, P, P, P]),
+    "uh_bn_relu_apply": (I, [L, I, P, I, I, P, P, P, P, I, I, P]),
+    "uh_bn_bwd_parts": (I, [L, I]),
+    "uh_bn_relu_bwd_reduce": (I, [L, I, P, I, I, P, I, I, P, P, P, P, P, P]),
+    "uh_bn_bwd_finalize": (I, [P, I, I, L, P, P, P, I, P]),
+    "uh_bn_relu_bwd_apply": (I, [L, I, P, I, I, P, I, I, P, P, P, P, P, P, P, I, I, P]),
+    "uh_maxpool2_fwd": (I, [I, I, I, I, P, I, I, P, I, I, P]),
+    "uh_maxpool2_bwd": (I, [I, I, I, I, P, I, I, P, I, I, P, I, I, P, I, I, P]),
+    "uh_space_to_depth2": (I, [I, I, I, I, P, I, I, P, I, I, P]),
+    "uh_depth_to_space2": (I, [I, I, I, I, P, I, I, P, I, I, P]),
+    "uh_colsum_parts": (I, [L, I]),
+    "uh_colsum": (I, [L, I, P, I, I, P, P]),
+    "uh_colsum_finalize": (I, [P, I, I, I, P, I, P]),
+    "uh_head_fwd": (I, [I, I, I, I, I, P, I, I, P, P, P, P]),
+    "uh_head_bwd_parts": (I, [I, I, I]),
+    "uh_head_bwd": (I, [I, I, I, I, I, P, I, I, P, P, P, I, I, P, P]),
+}
+
+EPI_RAW_STATS, EPI_AFFINE_RELU, EPI_MASKED, EPI_CONVT = 0, 1, 2, 3
+
+
+class HipLibraryMissing(ImportError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing(
+            f"{LIB_PATH} not found: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no fallback path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+class HipKernelError(RuntimeError):
+    pass
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = lib.uh_last_error().decode("utf-8", "replace")
+        raise HipKernelError(f"{what}: uh_status {status}: {msg}")
+
+
+def call(name, *args):
+    """Call an int-status entry point and raise on error."""
+    st = getattr(lib, name)(*args)
+    if st != 0:
+        check(st, name)

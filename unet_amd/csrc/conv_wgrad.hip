@@ -1,0 +1,224 @@
+// Weight gradient of the implicit-GEMM convolution on gfx950 matrix cores.
+//
+//   dW[n][t][k] = sum_m dY[m][n] * A[m + off(t)][k]
+//
+// The reduction runs over the rows (pixels) of two padded-linear NHWC tensors, so BOTH MFMA
+// operands must be read "down the columns" of their LDS tiles.  The tiles are staged as they
+// sit in memory ([pixel][channel], 128 B per pixel row, global_load_lds) and the fragments are
+// read with ds_read_b64_tr_b16, the gfx950 transposing LDS read: each 16-lane group fetches a
+// 4-pixel x 16-channel block and every lane receives the 4 pixels of ONE channel.
+// One workgroup owns a 64(n) x 64(k) x T block of dW and a contiguous range of pixels; per
+// 128-pixel stage it keeps dY[128][64] and, for T = 9, three row bands of A (dy = -1,0,+1,
+// 136 pixel rows each) so that all nine taps are served from LDS.  Each wave owns one 16-wide
+// k slice: 4 (n) x T accumulator tiles.  Partial results of the pixel splits are written to a
+// workspace slab and summed by uh_wgrad_reduce (deterministic, no atomics).
+#include "common.h"
+
+struct WgradArgs {
+  const char* dY;
+  const char* A;
+  float* partial;
+  long long Mp;
+  long long rows_per_split;  // multiple of 128
+  int dy_cstride, dy_coff, a_cstride, a_coff;
+  int N, K, Wp;
+};
+
+template <int T>
+struct WCfg {
+  static constexpr int BANDS = (T == 9) ? 3 : 1;
+  static constexpr int BAND_GROUPS = (T == 9) ? 17 : 16;  // 8-row groups per band (T=9: 130 rows needed)
+  static constexpr int DY_BYTES = 128 * 128;
+  static constexpr int BAND_BYTES = BAND_GROUPS * 1024;
+  static constexpr int LDS_BYTES = DY_BYTES + BANDS * BAND_BYTES;
+  static constexpr int NGROUPS = 16 + BANDS * BAND_GROUPS;
+};
+
+template <int T>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs p) {
+  using C = WCfg<T>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+  const int split = blockIdx.z;
+  const long long ms = (long long)split * p.rows_per_split;
+  long long me = ms + p.rows_per_split;
+  if (me > ((p.Mp + 127) / 128) * 128) me = ((p.Mp + 127) / 128) * 128;
+
+  // staging: LDS row r keeps source chunk c at position c ^ (((r>>1)&3)<<1); an 8-row group
+  // always starts at a multiple of 8, so the swizzle depends on the lane only.
+  const int lrow = lane >> 3;
+  const int src_chunk = (lane & 7) ^ (((lane >> 4) & 3) << 1);
+  const long long dy_row_bytes = (long long)p.dy_cstride * 2, a_row_bytes = (long long)p.a_cstride * 2;
+  const char* dy_lane = p.dY + (long long)lrow * dy_row_bytes + (long long)(p.dy_coff + n0) * 2 + src_chunk * 16;
+  const char* a_lane = p.A + (long long)lrow * a_row_bytes + (long long)(p.a_coff + k0) * 2 + src_chunk * 16;
+
+  // transposed-read lane geometry: group g = lane/16 reads pixels 4g+q (first read) and 16+4g+q
+  // (second read); q = (lane/4)&3 is the block row this lane addresses, pc = lane&3 the 4-channel column.
+  const int g = lane >> 4, q = (lane >> 2) & 3, pc = lane & 3;
+  const int px = 4 * g + q;                       // pixel of the first read within a 32-pixel k-step
+
+  f32x4 acc[T][4];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (long long mb = ms; mb < me; mb += 128) {
+    __syncthreads();  // previous stage fully consumed
+    // ---- stage dY[128 rows] and the A bands -------------------------------------------------
+    for (int gi = wave; gi < C::NGROUPS; gi += 4) {
+      const char* src;
+      if (gi < 16) {
+        src = dy_lane + (mb + gi * 8) * dy_row_bytes;
+      } else {
+        const int band = (gi - 16) / C::BAND_GROUPS, bg = (gi - 16) % C::BAND_GROUPS;
+        const long long r0 = (T == 9) ? (mb + (long long)(band - 1) * p.Wp - 1) : mb;
+        src = a_lane + (r0 + bg * 8) * a_row_bytes;
+      }
+      __builtin_amdgcn_global_load_lds((const UH_GLOBAL void*)src, (UH_LDS void*)(smem + gi * 1024), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      // A-operand fragments: dY^T, 4 n-subtiles of 16 channels
+      bf16x8 af[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        bf16x4 lo, hi;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int r = ks * 32 + px + 16 * h;
+          const int chunk = (2 * i + (pc >> 1)) ^ (((r >> 1) & 3) << 1);
+          const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+              (UH_LDS bf16x4*)(smem + r * 128 + chunk * 16 + (pc & 1) * 8));
+          if (h == 0) lo = v; else hi = v;
+        }
+        af[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const int band = (T == 9) ? t / 3 : 0;
+        const int kx = (T == 9) ? t % 3 : 0;
+        bf16x4 lo, hi;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int r = ks * 32 + px + 16 * h + kx;   // row inside the band
+          const int chunk = (2 * wave + (pc >> 1)) ^ (((r >> 1) & 3) << 1);
+          const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+              (UH_LDS bf16x4*)(smem + C::DY_BYTES + band * C::BAND_BYTES + r * 128 + chunk * 16 + (pc & 1) * 8));
+          if (h == 0) lo = v; else hi = v;
+        }
+        const bf16x8 bfr = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr, acc[t][i], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- store the partial block: partial[split][n][t][k] -----------------------------------
+  const int l15 = lane & 15;
+  float* base = p.partial + (long long)split * p.N * T * p.K;
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = n0 + i * 16 + g * 4 + e;
+        const int k = k0 + wave * 16 + l15;
+        base[((long long)n * T + t) * p.K + k] = acc[t][i][e];
+      }
+}
+
+static int wgrad_splits(long long Mp, int N, int K) {
+  const long long stages = (Mp + 127) / 128;
+  const long long tiles = (long long)(N / 64) * (K / 64);
+  long long want = (1024 + tiles - 1) / tiles;       // aim at ~1024 workgroups
+  if (want > stages) want = stages;
+  if (want < 1) want = 1;
+  if (want > 512) want = 512;
+  return (int)want;
+}
+
+extern "C" int uh_conv_wgrad_splits(int B, int H, int W, int N, int K, int T) {
+  (void)T;
+  return wgrad_splits(uh_mp(B, H, W), N, K);
+}
+
+extern "C" size_t uh_conv_wgrad_workspace(int B, int H, int W, int N, int K, int T) {
+  return (size_t)wgrad_splits(uh_mp(B, H, W), N, K) * N * T * K * sizeof(float);
+}
+
+extern "C" int uh_conv_wgrad(int B, int H, int W, const void* dy, int dy_cstride, int dy_coff, int N,
+                             const void* a, int a_cstride, int a_coff, int K, int T, float* partial,
+                             uh_stream s) {
+  UH_REQUIRE(B > 0 && H > 0 && W > 0, "conv_wgrad: bad geometry");
+  UH_REQUIRE(N > 0 && N % 64 == 0 && K > 0 && K % 64 == 0, "conv_wgrad: N=%d K=%d must be multiples of 64", N, K);
+  UH_REQUIRE(T == 1 || T == 9, "conv_wgrad: T=%d must be 1 or 9", T);
+  UH_REQUIRE(dy && a && partial, "conv_wgrad: null pointer");
+  UH_REQUIRE(dy_cstride >= dy_coff + N && a_cstride >= a_coff + K && dy_cstride % 8 == 0 && a_cstride % 8 == 0 &&
+                 dy_coff % 8 == 0 && a_coff % 8 == 0, "conv_wgrad: bad views");
+  WgradArgs p;
+  p.dY = (const char*)dy;
+  p.A = (const char*)a;
+  p.partial = partial;
+  p.Mp = uh_mp(B, H, W);
+  const int S = wgrad_splits(p.Mp, N, K);
+  const long long stages = (p.Mp + 127) / 128;
+  p.rows_per_split = ((stages + S - 1) / S) * 128;
+  p.dy_cstride = dy_cstride;
+  p.dy_coff = dy_coff;
+  p.a_cstride = a_cstride;
+  p.a_coff = a_coff;
+  p.N = N;
+  p.K = K;
+  p.Wp = W + 1;
+  dim3 grid(N / 64, K / 64, S);
+  hipStream_t st = (hipStream_t)s;
+  if (T == 9) {
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, WCfg<9>::LDS_BYTES);
+      attr = true;
+    }
+    hipLaunchKernelGGL((conv_wgrad_kernel<9>), grid, dim3(256), WCfg<9>::LDS_BYTES, st, p);
+  } else {
+    hipLaunchKernelGGL((conv_wgrad_kernel<1>), grid, dim3(256), WCfg<1>::LDS_BYTES, st, p);
+  }
+  return uh_check_launch("conv_wgrad");
+}
+
+// grad[n*sn + t*st + k*sk] (+)= sum_s partial[s*N*T*K + n*on + t*ot + k]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int S, int N, int T, int K, long long on,
+                                    long long ot, long long sn, long long st, long long sk, float* __restrict__ grad,
+                                    int accumulate) {
+  const long long total = (long long)N * T * K;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % K);
+    const long long r = i / K;
+    const int t = (int)(r % T);
+    const int n = (int)(r / T);
+    const long long src = n * on + t * ot + k;
+    float v = 0.f;
+    for (int s = 0; s < S; ++s) v += partial[s * total + src];
+    const long long dst = n * sn + t * st + k * sk;
+    grad[dst] = accumulate ? grad[dst] + v : v;
+  }
+}
+
+extern "C" int uh_wgrad_reduce(const float* partial, int S, int N, int T, int K, long long on, long long ot,
+                               long long sn, long long st, long long sk, float* grad, int accumulate, uh_stream s) {
+  UH_REQUIRE(partial && grad && S > 0 && N > 0 && T > 0 && K > 0, "wgrad_reduce: bad arguments");
+  const long long total = (long long)N * T * K;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, partial, S, N, T, K, on, ot, sn,
+                     st, sk, grad, accumulate);
+  return uh_check_launch("wgrad_reduce");
+}

@@ -1,0 +1,129 @@
+// Error plumbing, geometry helpers, weight packing, row masks, layout shuffles (space<->depth).
+#include <stdarg.h>
+#include <stdio.h>
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void uh_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int uh_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    uh_set_error("%s: HIP launch failed: %s", what, hipGetErrorString(e));
+    return UH_ERR_HIP;
+  }
+  return UH_OK;
+}
+
+extern "C" const char* uh_last_error(void) { return g_err; }
+extern "C" int uh_version(void) { return 1; }
+// (W+1)+1 rows cover the 3x3 neighbourhood of the first/last row; 256 more cover the overhang
+// of the last M tile (tiles are at most 256 rows) and of the last 128-row wgrad stage.
+extern "C" int uh_guard_rows(int W) { return W + 2 + 256 + 8; }
+
+__global__ void rowmask_kernel(int H, int W, long long Mp, uint8_t* mask) {
+  const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= Mp) return;
+  const int Wp = W + 1, Hp = H + 1;
+  const int x = (int)(m % Wp);
+  const int y = (int)((m / Wp) % Hp);
+  mask[m] = (x < W && y < H) ? 1 : 0;
+}
+
+extern "C" int uh_rowmask_build(int B, int H, int W, uint8_t* rowmask, uh_stream s) {
+  UH_REQUIRE(B > 0 && H > 0 && W > 0 && rowmask, "rowmask_build: bad arguments");
+  const long long Mp = uh_mp(B, H, W);
+  hipLaunchKernelGGL(rowmask_kernel, dim3((unsigned)((Mp + 255) / 256)), dim3(256), 0, (hipStream_t)s, H, W, Mp, rowmask);
+  return uh_check_launch("rowmask_build");
+}
+
+// dst[n*on + t*ot + k] = bf16(src[n*sn + tmap(t)*st + k*sk])
+__global__ void pack_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int N, int T, int K, long long sn,
+                            long long st, long long sk, long long on, long long ot, int reverse) {
+  const long long total = (long long)N * T * K;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % K);
+    const long long r = i / K;
+    const int t = (int)(r % T);
+    const int n = (int)(r / T);
+    const int ts = reverse ? (T - 1 - t) : t;
+    dst[n * on + t * ot + k] = f2bf(src[n * sn + ts * st + k * sk]);
+  }
+}
+
+extern "C" int uh_pack_weights(const float* src, void* dst, int N, int T, int K, long long sn, long long st,
+                               long long sk, long long on, long long ot, int reverse, uh_stream s) {
+  UH_REQUIRE(src && dst && N > 0 && T > 0 && K > 0, "pack_weights: bad arguments");
+  const long long total = (long long)N * T * K;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, src, (bf16*)dst, N, T, K, sn, st, sk, on,
+                     ot, reverse);
+  return uh_check_launch("pack_weights");
+}
+
+// ---- space <-> depth for k2 s2 (transposed) convolutions -------------------------------------
+// Small geometry (B,H,W); large geometry (B,2H,2W).  One thread moves 8 channels of one
+// (small position, tap); every row of the destination, pads included, is written exactly once.
+template <bool TO_DEPTH>
+__global__ void s2d_kernel(int B, int H, int W, int C, const char* __restrict__ in, int i_cstride, int i_coff,
+                           char* __restrict__ out, int o_cstride, int o_coff) {
+  const int Wp = W + 1, Hp = H + 1, oWp = 2 * W + 1, oHp = 2 * H + 1;
+  const int cpr = C / 8;
+  const long long total = (long long)B * Hp * Wp * 4 * cpr;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % cpr);
+    long long r = i / cpr;
+    const int t = (int)(r & 3);
+    r >>= 2;
+    const int x = (int)(r % Wp);
+    r /= Wp;
+    const int y = (int)(r % Hp);
+    const long long b = r / Hp;
+    const long long ms = (b * Hp + y) * Wp + x;
+    const int Y = 2 * y + (t >> 1), X = 2 * x + (t & 1);
+    const bool big_ok = (Y < oHp && X < oWp);
+    const long long mb = (b * oHp + Y) * oWp + X;
+    const bool interior = (y < H && x < W);
+    U4 v = {0u, 0u, 0u, 0u};
+    if (TO_DEPTH) {
+      if (interior && big_ok) v = *(const U4*)(in + (mb * i_cstride + i_coff + cc * 8) * 2);
+      *(U4*)(out + (ms * o_cstride + o_coff + t * C + cc * 8) * 2) = v;
+    } else {
+      if (!big_ok) continue;
+      if (interior) v = *(const U4*)(in + (ms * i_cstride + i_coff + t * C + cc * 8) * 2);
+      *(U4*)(out + (mb * o_cstride + o_coff + cc * 8) * 2) = v;
+    }
+  }
+}
+
+static int s2d_launch(bool to_depth, int B, int H, int W, int C, const void* in, int i_cstride, int i_coff, void* out,
+                      int o_cstride, int o_coff, uh_stream s) {
+  UH_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && in && out, "space/depth: bad arguments");
+  UH_REQUIRE(i_cstride % 8 == 0 && i_coff % 8 == 0 && o_cstride % 8 == 0 && o_coff % 8 == 0, "space/depth: bad views");
+  const long long total = uh_mp(B, H, W) * 4 * (C / 8);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 16384) blocks = 16384;
+  if (to_depth)
+    hipLaunchKernelGGL((s2d_kernel<true>), dim3(blocks), dim3(256), 0, (hipStream_t)s, B, H, W, C, (const char*)in,
+                       i_cstride, i_coff, (char*)out, o_cstride, o_coff);
+  else
+    hipLaunchKernelGGL((s2d_kernel<false>), dim3(blocks), dim3(256), 0, (hipStream_t)s, B, H, W, C, (const char*)in,
+                       i_cstride, i_coff, (char*)out, o_cstride, o_coff);
+  return uh_check_launch("space/depth");
+}
+
+extern "C" int uh_space_to_depth2(int B, int H, int W, int C, const void* in, int i_cstride, int i_coff, void* out,
+                                  int o_cstride, int o_coff, uh_stream s) {
+  return s2d_launch(true, B, H, W, C, in, i_cstride, i_coff, out, o_cstride, o_coff, s);
+}
+extern "C" int uh_depth_to_space2(int B, int H, int W, int C, const void* in, int i_cstride, int i_coff, void* out,
+                                  int o_cstride, int o_coff, uh_stream s) {
+  return s2d_launch(false, B, H, W, C, in, i_cstride, i_coff, out, o_cstride, o_coff, s);
+}

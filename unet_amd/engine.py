@@ -1,0 +1,304 @@
+"""Host-side schedule of the U-Net forward and backward passes over the HIP kernels.
+
+The layer order, channel widths, skip wiring and what is saved follow models/unet.py:86-176 of
+the reference; everything the device executes is an entry point of libunet_hip.so.  One
+`UNetRun` object holds the buffers of one forward pass and can run its backward pass.
+"""
+import torch
+
+from . import _lib
+from ._lib import call, EPI_RAW_STATS, EPI_AFFINE_RELU, EPI_MASKED, EPI_CONVT
+from .layout import pool_for
+
+BN_EPS = 1e-5        # nn.BatchNorm2d defaults used by the reference (unet.py:20)
+BN_MOMENTUM = 0.1
+
+WIDTHS = (64, 128, 256, 512, 1024)
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+class _ConvRec:
+    """Saved state of one conv3x3+BN+ReLU layer."""
+    __slots__ = ("name", "a_in", "y", "a_out", "cin", "cout", "mean", "invstd", "scale", "shift")
+
+
+class UNetRun:
+    """One forward pass (and optionally its backward) of the U-Net on one device."""
+
+    def __init__(self, module, x, training):
+        self.m = module
+        self.training = training
+        self.device = x.device
+        self.pool = pool_for(x.device)
+        self.lease = self.pool.lease()
+        B, Cin, H, W = x.shape
+        if H % 16 or W % 16:
+            raise ValueError(f"UNet needs H and W divisible by 16 (four 2x2 poolings), got {H}x{W}")
+        if Cin != module.in_channels:
+            raise ValueError(f"expected {module.in_channels} input channels, got {Cin}")
+        if Cin > 4:
+            raise NotImplementedError("the first-layer kernel is built for in_channels <= 4")
+        self.B, self.H, self.W, self.Cin = B, H, W, Cin
+        self.x = x
+        self.recs = {}
+        self.geo = [(B, H >> l, W >> l) for l in range(5)]
+        self.masks = [self.pool.rowmask(*g) for g in self.geo]
+
+    # ------------------------------------------------------------------ helpers
+    def _pack(self, w, N, T, K, sn, st, sk, on, ot, reverse=0):
+        dst = self.lease.bf16_flat(N * T * K)
+        call("uh_pack_weights", w.data_ptr(), dst.data_ptr(), N, T, K, sn, st, sk, on, ot, reverse, _stream())
+        return dst
+
+    def _bn_params(self, C):
+        f = self.lease.f32(4 * C)
+        return f[0:C], f[C:2 * C], f[2 * C:3 * C], f[3 * C:4 * C]     # mean, invstd, scale, shift
+
+    def _finish_bn(self, rec, lvl, stat, parts, conv, bn):
+        """statistics -> scale/shift (+ running stats), then a_out = relu(y*scale+shift)."""
+        B, H, W = self.geo[lvl]
+        C = rec.cout
+        rec.mean, rec.invstd, rec.scale, rec.shift = self._bn_params(C)
+        call("uh_bn_finalize", stat.data_ptr(), parts, C, B * H * W, bn.weight.data_ptr(), bn.bias.data_ptr(),
+             BN_EPS, BN_MOMENTUM, rec.mean.data_ptr(), rec.invstd.data_ptr(), rec.scale.data_ptr(),
+             rec.shift.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+             bn.num_batches_tracked.data_ptr(), _stream())
+        y, a = rec.y, rec.a_out
+        call("uh_bn_relu_apply", y.Mp, C, y.ptr, y.cstride, y.coff, rec.scale.data_ptr(), rec.shift.data_ptr(),
+             self.masks[lvl].data_ptr(), a.ptr, a.cstride, a.coff, _stream())
+
+    def _cbr(self, name, a_in, lvl, a_out):
+        """conv3x3 + BN + ReLU (unet.py:99 etc.).  a_in is None for the first layer (reads self.x)."""
+        conv = getattr(self.m, name)
+        bn = getattr(self.m, name.replace("conv", "bn", 1))
+        B, H, W = self.geo[lvl]
+        cout = conv.out_channels
+        cin = conv.in_channels
+        rec = _ConvRec()
+        rec.name, rec.a_in, rec.a_out, rec.cin, rec.cout = name, a_in, a_out, cin, cout
+        s = _stream()
+        if self.training:
+            rec.y = self.lease.act(B, H, W, cout)
+            if a_in is None:
+                parts = _lib.lib.uh_conv_first_parts(B, H, W)
+                stat = self.lease.f32(parts * 2 * cout)
+                call("uh_conv_first_fwd", B, H, W, cin, cout, self.x.data_ptr(), conv.weight.data_ptr(),
+                     conv.bias.data_ptr(), EPI_RAW_STATS, None, None, rec.y.ptr, rec.y.cstride, rec.y.coff,
+                     stat.data_ptr(), s)
+            else:
+                wp = self._pack(conv.weight, cout, 9, cin, cin * 9, 1, 9, 9 * cin, cin)
+                parts = _lib.lib.uh_conv_gemm_mtiles(B, H, W, cout)
+                stat = self.lease.f32(parts * 2 * cout)
+                call("uh_conv_gemm", B, H, W, a_in.ptr, a_in.cstride, a_in.coff, cin, wp.data_ptr(), cout, 9,
+                     EPI_RAW_STATS, rec.y.ptr, rec.y.cstride, rec.y.coff, conv.bias.data_ptr(), None, None,
+                     stat.data_ptr(), self.masks[lvl].data_ptr(), s)
+            self._finish_bn(rec, lvl, stat, parts, conv, bn)
+            self.recs[name] = rec
+        else:
+            f = self.lease.f32(2 * cout)
+            scale, shift = f[:cout], f[cout:]
+            call("uh_bn_fold_eval", cout, bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                 bn.running_var.data_ptr(), conv.bias.data_ptr(), BN_EPS, scale.data_ptr(), shift.data_ptr(), s)
+            if a_in is None:
+                call("uh_conv_first_fwd", B, H, W, cin, cout, self.x.data_ptr(), conv.weight.data_ptr(),
+                     conv.bias.data_ptr(), EPI_AFFINE_RELU, scale.data_ptr(), shift.data_ptr(), a_out.ptr,
+                     a_out.cstride, a_out.coff, None, s)
+            else:
+                wp = self._pack(conv.weight, cout, 9, cin, cin * 9, 1, 9, 9 * cin, cin)
+                call("uh_conv_gemm", B, H, W, a_in.ptr, a_in.cstride, a_in.coff, cin, wp.data_ptr(), cout, 9,
+                     EPI_AFFINE_RELU, a_out.ptr, a_out.cstride, a_out.coff, None, scale.data_ptr(),
+                     shift.data_ptr(), None, self.masks[lvl].data_ptr(), s)
+        return a_out
+
+    # ------------------------------------------------------------------ forward
+    def forward(self):
+        m, L = self.m, self.lease
+        s = _stream()
+        acts = {}
+        # concat buffers, one per decoder stage: [skip | upsampled] (unet.py:137,147,157,167)
+        cat = [L.act(*self.geo[l], WIDTHS[l], cstride=2 * WIDTHS[l]) for l in range(4)]
+        self.cat = cat
+        cur = None
+        for l in range(5):                                   # encoder + bridge (unet.py:99-128)
+            B, H, W = self.geo[l]
+            w = WIDTHS[l]
+            a1 = L.act(B, H, W, w)
+            self._cbr(f"conv{l + 1}_1", cur, l, a1)
+            a2 = cat[l].window(0, w) if l < 4 else L.act(B, H, W, w)
+            self._cbr(f"conv{l + 1}_2", a1, l, a2)
+            acts[f"conv{l + 1}_1"], acts[f"conv{l + 1}_2"] = a1, a2
+            if l < 4:
+                p = L.act(B, H // 2, W // 2, w)
+                call("uh_maxpool2_fwd", B, H, W, w, a2.ptr, a2.cstride, a2.coff, p.ptr, p.cstride, p.coff, s)
+                acts[f"pool{l + 1}"] = p
+                cur = p
+            else:
+                cur = a2
+        for k in range(1, 5):                                # decoder (unet.py:132-169)
+            l = 4 - k                                        # level of the output
+            w = WIDTHS[l]
+            up = getattr(m, f"upconv{k}")
+            Bs, Hs, Ws = self.geo[l + 1]
+            # W[ci][co][a][b] -> GEMM rows n = (a*2+b)*Cout + co
+            wp = self._pack(up.weight, w, 4, 2 * w, 4, 1, w * 4, 2 * w, w * 2 * w)
+            dst = cat[l].window(w, w)
+            call("uh_conv_gemm", Bs, Hs, Ws, cur.ptr, cur.cstride, cur.coff, 2 * w, wp.data_ptr(), 4 * w, 1,
+                 EPI_CONVT, dst.ptr, dst.cstride, dst.coff, up.bias.data_ptr(), None, None, None,
+                 self.masks[l + 1].data_ptr(), s)
+            acts[f"upconv{k}_in"] = cur
+            B, H, W = self.geo[l]
+            a1 = L.act(B, H, W, w)
+            self._cbr(f"conv_up{k}_1", cat[l].window(0, 2 * w), l, a1)
+            a2 = L.act(B, H, W, w)
+            self._cbr(f"conv_up{k}_2", a1, l, a2)
+            acts[f"conv_up{k}_1"], acts[f"conv_up{k}_2"] = a1, a2
+            cur = a2
+        oc = m.out_channels
+        logits = torch.empty(self.B, oc, self.H, self.W, dtype=torch.float32, device=self.device)
+        fc = m.final_conv
+        call("uh_head_fwd", self.B, self.H, self.W, 64, oc, cur.ptr, cur.cstride, cur.coff, fc.weight.data_ptr(),
+             fc.bias.data_ptr(), logits.data_ptr(), s)
+        self.acts = acts
+        self.head_in = cur
+        return logits
+
+    # ------------------------------------------------------------------ backward
+    def _cbr_backward(self, name, lvl, da, grads, want_dgrad=True):
+        """Backward of conv3x3+BN+ReLU.  `da` = gradient w.r.t. the layer's activated output.
+        Returns the gradient w.r.t. the layer's input activation (an Act with a_in's channel count)."""
+        rec = self.recs[name]
+        conv = getattr(self.m, name)
+        L, s = self.lease, _stream()
+        B, H, W = self.geo[lvl]
+        C, cin = rec.cout, rec.cin
+        y = rec.y
+        Mp = y.Mp
+        parts = _lib.lib.uh_bn_bwd_parts(Mp, C)
+        partial = L.f32(parts * 2 * C)
+        call("uh_bn_relu_bwd_reduce", Mp, C, da.ptr, da.cstride, da.coff, y.ptr, y.cstride, y.coff,
+             rec.mean.data_ptr(), rec.invstd.data_ptr(), rec.scale.data_ptr(), rec.shift.data_ptr(),
+             partial.data_ptr(), s)
+        bnname = name.replace("conv", "bn", 1)
+        dgamma = torch.empty(C, dtype=torch.float32, device=self.device)
+        dbeta = torch.empty(C, dtype=torch.float32, device=self.device)
+        coef = L.f32(2 * C)
+        call("uh_bn_bwd_finalize", partial.data_ptr(), parts, C, B * H * W, dgamma.data_ptr(), dbeta.data_ptr(),
+             coef.data_ptr(), 0, s)
+        grads[bnname + ".weight"], grads[bnname + ".bias"] = dgamma, dbeta
+        dy = L.act(B, H, W, C)
+        call("uh_bn_relu_bwd_apply", Mp, C, da.ptr, da.cstride, da.coff, y.ptr, y.cstride, y.coff,
+             rec.mean.data_ptr(), rec.invstd.data_ptr(), rec.scale.data_ptr(), rec.shift.data_ptr(),
+             coef.data_ptr(), self.masks[lvl].data_ptr(), dy.ptr, dy.cstride, dy.coff, s)
+        # the bias of a conv that feeds train-mode BatchNorm has an exactly zero gradient:
+        # BN subtracts the batch mean, so sum_m dy[m][c] == 0 for every channel.
+        grads[name + ".bias"] = torch.zeros(C, dtype=torch.float32, device=self.device)
+        dw = torch.empty_like(conv.weight)
+        if rec.a_in is None:
+            parts = _lib.lib.uh_conv_first_wgrad_parts(B, H, W)
+            wpart = L.f32(parts * C * cin * 9)
+            call("uh_conv_first_wgrad", B, H, W, cin, C, self.x.data_ptr(), dy.ptr, dy.cstride, dy.coff,
+                 wpart.data_ptr(), s)
+            call("uh_wgrad_reduce", wpart.data_ptr(), parts, C, 1, cin * 9, cin * 9, 0, cin * 9, 0, 1,
+                 dw.data_ptr(), 0, s)
+            grads[name + ".weight"] = dw
+            return None
+        a_in = rec.a_in
+        S = _lib.lib.uh_conv_wgrad_splits(B, H, W, C, cin, 9)
+        wpart = L.f32(S * C * 9 * cin)
+        call("uh_conv_wgrad", B, H, W, dy.ptr, dy.cstride, dy.coff, C, a_in.ptr, a_in.cstride, a_in.coff, cin, 9,
+             wpart.data_ptr(), s)
+        # partial [n][t][k] -> OIHW: grad[n*cin*9 + k*9 + t]
+        call("uh_wgrad_reduce", wpart.data_ptr(), S, C, 9, cin, 9 * cin, cin, cin * 9, 1, 9, dw.data_ptr(), 0, s)
+        grads[name + ".weight"] = dw
+        if not want_dgrad:
+            return None
+        # dgrad: dx[m][ci] = sum_t sum_co dy[m + off(t)][co] * W[co][ci][8-t]
+        wd = self._pack(conv.weight, cin, 9, C, 9, 1, cin * 9, 9 * C, C, reverse=1)
+        dx = L.act(B, H, W, cin)
+        call("uh_conv_gemm", B, H, W, dy.ptr, dy.cstride, dy.coff, C, wd.data_ptr(), cin, 9, EPI_MASKED,
+             dx.ptr, dx.cstride, dx.coff, None, None, None, None, self.masks[lvl].data_ptr(), s)
+        return dx
+
+    def backward(self, dlogits):
+        """Returns {parameter name: fp32 gradient} for every parameter of the module."""
+        if not self.training:
+            raise RuntimeError("backward through an eval-mode (running-statistics) forward is not built; "
+                               "call model.train() before a forward pass that needs gradients")
+        m, L, s = self.m, self.lease, _stream()
+        grads = {}
+        dl = dlogits.contiguous().float()
+        oc = m.out_channels
+        B, H, W = self.geo[0]
+        a = self.head_in
+        fc = m.final_conv
+        da = L.act(B, H, W, 64)
+        parts = _lib.lib.uh_head_bwd_parts(B, H, W)
+        hp = L.f32(parts * oc * 65)
+        call("uh_head_bwd", B, H, W, 64, oc, a.ptr, a.cstride, a.coff, fc.weight.data_ptr(), dl.data_ptr(),
+             da.ptr, da.cstride, da.coff, hp.data_ptr(), s)
+        hw = torch.empty(oc * 65, dtype=torch.float32, device=self.device)
+        call("uh_colsum_finalize", hp.data_ptr(), parts, oc * 65, 1, hw.data_ptr(), 0, s)
+        hw = hw.view(oc, 65)
+        grads["final_conv.weight"] = hw[:, :64].reshape(oc, 64, 1, 1).contiguous()
+        grads["final_conv.bias"] = hw[:, 64].contiguous()
+
+        skip_grads = [None] * 4
+        for k in range(4, 0, -1):                            # decoder, last stage first
+            l = 4 - k
+            w = WIDTHS[l]
+            B, H, W = self.geo[l]
+            da = self._cbr_backward(f"conv_up{k}_2", l, da, grads)
+            dcat = self._cbr_backward(f"conv_up{k}_1", l, da, grads)     # [Mp][2w]
+            skip_grads[l] = dcat.window(0, w)
+            dup = dcat.window(w, w)
+            up = getattr(m, f"upconv{k}")
+            # bias gradient of the transposed conv: column sums of its output gradient
+            parts = _lib.lib.uh_colsum_parts(dup.Mp, w)
+            cp = L.f32(parts * w)
+            call("uh_colsum", dup.Mp, w, dup.ptr, dup.cstride, dup.coff, cp.data_ptr(), s)
+            db = torch.empty(w, dtype=torch.float32, device=self.device)
+            call("uh_colsum_finalize", cp.data_ptr(), parts, w, 1, db.data_ptr(), 0, s)
+            grads[f"upconv{k}.bias"] = db
+            # gather the 2x2 output positions of every input position: d4[m][t*w + co]
+            Bs, Hs, Ws = self.geo[l + 1]
+            d4 = L.act(Bs, Hs, Ws, 4 * w)
+            call("uh_space_to_depth2", Bs, Hs, Ws, w, dup.ptr, dup.cstride, dup.coff, d4.ptr, d4.cstride, d4.coff, s)
+            a_in = self.acts[f"upconv{k}_in"]
+            cin = 2 * w
+            S = _lib.lib.uh_conv_wgrad_splits(Bs, Hs, Ws, 4 * w, cin, 1)
+            wpart = L.f32(S * 4 * w * cin)
+            call("uh_conv_wgrad", Bs, Hs, Ws, d4.ptr, d4.cstride, d4.coff, 4 * w, a_in.ptr, a_in.cstride, a_in.coff,
+                 cin, 1, wpart.data_ptr(), s)
+            dw = torch.empty_like(up.weight)                 # [cin][w][2][2]
+            call("uh_wgrad_reduce", wpart.data_ptr(), S, w, 4, cin, cin, w * cin, 4, 1, w * 4, dw.data_ptr(), 0, s)
+            grads[f"upconv{k}.weight"] = dw
+            # input gradient: dx[m][ci] = sum_{t,co} d4[m][t*w+co] * W[ci][co][t]
+            wd = self._pack(up.weight, cin, 4, w, w * 4, 1, 4, 4 * w, w)
+            da = L.act(Bs, Hs, Ws, cin)
+            call("uh_conv_gemm", Bs, Hs, Ws, d4.ptr, d4.cstride, d4.coff, 4 * w, wd.data_ptr(), cin, 1, EPI_MASKED,
+                 da.ptr, da.cstride, da.coff, None, None, None, None, self.masks[l + 1].data_ptr(), s)
+        for l in range(4, -1, -1):                           # bridge, then encoder levels 3..0
+            w = WIDTHS[l]
+            B, H, W = self.geo[l]
+            if l < 4:
+                a2 = self.acts[f"conv{l + 1}_2"]
+                sg = skip_grads[l]
+                dsum = L.act(B, H, W, w)
+                call("uh_maxpool2_bwd", B, H, W, w, a2.ptr, a2.cstride, a2.coff, da.ptr, da.cstride, da.coff,
+                     sg.ptr, sg.cstride, sg.coff, dsum.ptr, dsum.cstride, dsum.coff, s)
+                da = dsum
+            da = self._cbr_backward(f"conv{l + 1}_2", l, da, grads)
+            da = self._cbr_backward(f"conv{l + 1}_1", l, da, grads, want_dgrad=(l > 0))
+        return grads
+
+    def release(self):
+        self.recs = {}
+        self.acts = {}
+        self.lease.release()
