@@ -48,7 +48,7 @@ int uh_pack_weights(const float* src, void* dst_bf16, int N, int T, int K,
  * T=1 GEMM with a pixel-shuffle store, and 1x1 / 2x2-stride-2 convs after space-to-depth (lunext.py).
  * K and N must be multiples of 64.  Epilogue modes: */
 enum {
-  UH_EPI_RAW_STATS = 0,   /* out = bf16(acc + bias), zero on pad rows; per-M-tile channel sums of v and v*v
+  UH_EPI_RAW_STATS = 0,   /* out = fp16(acc + bias) (IEEE half, same 2-byte rows), zero on pad rows; per-M-tile channel sums of v and v*v
                              over interior rows -> stat_partial[mtile][2][N]   (train-mode BN input) */
   UH_EPI_AFFINE_RELU = 1, /* out = relu(acc*scale[n] + shift[n]) on interior rows, 0 on pads (eval-mode BN folded) */
   UH_EPI_MASKED = 2,      /* out = acc (+bias if given) on interior rows, 0 on pads (dgrad, plain convs) */
@@ -99,7 +99,7 @@ int uh_bn_finalize(const float* partial, int P, int C, long long count,
 /* eval mode: scale = gamma/sqrt(rv+eps); shift = beta + (conv_bias - rm)*scale */
 int uh_bn_fold_eval(int C, const float* gamma, const float* beta, const float* rm, const float* rv,
                     const float* conv_bias, float eps, float* scale, float* shift, uh_stream s);
-/* a = relu(y*scale + shift) on interior rows, 0 on pads */
+/* a = relu(y*scale + shift) on interior rows, 0 on pads; y is the fp16 RAW_STATS output, a is bf16 */
 int uh_bn_relu_apply(long long Mp, int C, const void* y, int y_cstride, int y_coff,
                      const float* scale, const float* shift, const uint8_t* rowmask,
                      void* a, int a_cstride, int a_coff, uh_stream s);

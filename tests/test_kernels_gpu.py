@@ -26,10 +26,10 @@ def bf(t):
     return t.to(torch.bfloat16).float()
 
 
-def act_from(t, cstride=None, coff=0):
+def act_from(t, cstride=None, coff=0, half=False):
     B, C, H, W = t.shape
     a = new_act(B, H, W, cstride or C, DEV, cstride=cstride or C).window(coff, C)
-    a.fill_from_nchw(t.to(DEV))
+    a.fill_from_nchw(t.to(DEV), half=half)
     return a
 
 
@@ -81,11 +81,12 @@ def test_conv_gemm_raw_stats(B, H, W, Cin, Cout):
     parts = lib.uh_conv_gemm_mtiles(B, H, W, Cout)
     stat = torch.zeros(parts, 2, Cout, device=DEV)
     bd = b.to(DEV)
-    call("uh_conv_gemm", B, H, W, a.ptr, a.cstride, a.coff, Cin, pack_conv(wd).data_ptr(), Cout, 9, _lib.EPI_RAW_STATS,
+    pk = pack_conv(wd)          # keep the packed weights alive until the kernel has run
+    call("uh_conv_gemm", B, H, W, a.ptr, a.cstride, a.coff, Cin, pk.data_ptr(), Cout, 9, _lib.EPI_RAW_STATS,
          out.ptr, out.cstride, out.coff, bd.data_ptr(), None, None, stat.data_ptr(), rowmask(B, H, W).data_ptr(), S())
     torch.cuda.synchronize()
     want = F.conv2d(x, w, b, padding=1)
-    close(out.to_nchw(), want, 1e-2, "conv output (bf16 store: 2^-8 relative)")
+    close(out.to_nchw(half=True), want, 2e-3, "conv output (fp16 store)")
     pads_are_zero(out)
     s = stat.sum(0).cpu()
     close(s[0], want.sum((0, 2, 3)), 2e-3, "sum y")
@@ -102,7 +103,8 @@ def test_conv_gemm_affine_relu_and_views():
     a = act_from(x, cstride=192, coff=64)
     out = new_act(B, H, W, 256, DEV, cstride=256).window(128, Cout)
     wd, sc, sh = w.to(DEV), scale.to(DEV), shift.to(DEV)
-    call("uh_conv_gemm", B, H, W, a.ptr, a.cstride, a.coff, Cin, pack_conv(wd).data_ptr(), Cout, 9,
+    pk = pack_conv(wd)
+    call("uh_conv_gemm", B, H, W, a.ptr, a.cstride, a.coff, Cin, pk.data_ptr(), Cout, 9,
          _lib.EPI_AFFINE_RELU, out.ptr, out.cstride, out.coff, None, sc.data_ptr(), sh.data_ptr(), None,
          rowmask(B, H, W).data_ptr(), S())
     torch.cuda.synchronize()
@@ -228,7 +230,7 @@ def test_conv_first(Cin):
          None, None, out.ptr, out.cstride, out.coff, stat.data_ptr(), S())
     torch.cuda.synchronize()
     want = F.conv2d(x, w, b, padding=1)
-    close(out.to_nchw(), want, 6e-3, "first conv")
+    close(out.to_nchw(half=True), want, 1e-3, "first conv (fp16 store)")
     pads_are_zero(out)
     s = stat.sum(0).cpu()
     close(s[0], want.sum((0, 2, 3)), 1e-4, "sum y (fp32 path)")
@@ -256,7 +258,7 @@ def test_conv_first(Cin):
 @pytest.mark.parametrize("B,H,W,C", [(2, 16, 16, 64), (3, 4, 6, 256), (1, 8, 8, 1024)])
 def test_batchnorm_relu_forward_backward(B, H, W, C):
     g = torch.Generator().manual_seed(43)
-    y = bf(torch.randn(B, C, H, W, generator=g) * 2 + 0.5)
+    y = (torch.randn(B, C, H, W, generator=g) * 2 + 0.5).half().float()   # BatchNorm input is stored as fp16
     gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
     rm0, rv0 = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
     # statistics come from the conv epilogue; emulate a two-row partial here
@@ -273,7 +275,7 @@ def test_batchnorm_relu_forward_backward(B, H, W, C):
     st = torch.empty(4, C, device=DEV)
     call("uh_bn_finalize", pd.data_ptr(), 2, C, B * H * W, gd.data_ptr(), bd.data_ptr(), 1e-5, 0.1, st[0].data_ptr(),
          st[1].data_ptr(), st[2].data_ptr(), st[3].data_ptr(), rm.data_ptr(), rv.data_ptr(), nbt.data_ptr(), S())
-    ya = act_from(y)
+    ya = act_from(y, half=True)
     a = new_act(B, H, W, C, DEV)
     mask = rowmask(B, H, W)
     call("uh_bn_relu_apply", ya.Mp, C, ya.ptr, ya.cstride, ya.coff, st[2].data_ptr(), st[3].data_ptr(), mask.data_ptr(),

@@ -33,7 +33,7 @@ def test_unet_small_matches_reference(golden_dir):
     model = ref_cpu.RefUNet(3, 1)
     cs = np.array([[p.detach().double().sum().item(), p.detach().double().abs().sum().item()]
                    for p in model.parameters()])
-    np.testing.assert_array_equal(cs, fx["param_checksums"])   # same seed -> same init, bit for bit
+    np.testing.assert_allclose(cs, fx["param_checksums"], rtol=1e-12)   # same seed -> same init
     x, m = torch.from_numpy(fx["x"]), torch.from_numpy(fx["mask"])
     model.train()
     logits = model(x)

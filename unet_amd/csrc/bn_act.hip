@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(long long Mp, int C,
     U4 o = {0u, 0u, 0u, 0u};
     if (rowmask[m]) {
       float f[8];
-      unpack8(*(const U4*)(y + (m * y_cs + y_co + cc * 8) * 2), f);
+      unpack8h(*(const U4*)(y + (m * y_cs + y_co + cc * 8) * 2), f);
 #pragma unroll
       for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j] * sc[j] + sh[j], 0.f);
       o = pack8(f);
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(long long Mp, i
     for (long long m = (long long)blockIdx.x * rpi + rr; m < Mp; m += (long long)gridDim.x * rpi) {
       float g[8], v[8];
       unpack8(*(const U4*)(da + (m * da_cs + da_co + cc * 8) * 2), g);
-      unpack8(*(const U4*)(y + (m * y_cs + y_co + cc * 8) * 2), v);
+      unpack8h(*(const U4*)(y + (m * y_cs + y_co + cc * 8) * 2), v);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float d = (v[j] * sc[j] + sh[j] > 0.f) ? g[j] : 0.f;
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(long long Mp, in
     if (rowmask[m]) {
       float g[8], v[8];
       unpack8(*(const U4*)(da + (m * da_cs + da_co + cc * 8) * 2), g);
-      unpack8(*(const U4*)(y + (m * y_cs + y_co + cc * 8) * 2), v);
+      unpack8h(*(const U4*)(y + (m * y_cs + y_co + cc * 8) * 2), v);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float d = (v[j] * sc[j] + sh[j] > 0.f) ? g[j] : 0.f;

@@ -70,6 +70,35 @@ __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
   return *reinterpret_cast<uint32_t*>(&v);
 }
 
+// fp16 variants: the raw convolution output that feeds train-mode BatchNorm is stored as IEEE
+// half (11 significant bits).  BatchNorm subtracts the batch mean, which amplifies the storage
+// rounding of its input by |mean|/std; bf16 (8 bits) there costs ~10x the end-to-end error of
+// every other bf16 rounding in the network.  Values are clamped to the finite half range.
+__device__ __forceinline__ void unpack8h(const U4& u, float (&f)[8]) {
+  typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+  const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const h2 v = *reinterpret_cast<const h2*>(&w[i]);
+    f[2 * i] = (float)v[0];
+    f[2 * i + 1] = (float)v[1];
+  }
+}
+__device__ __forceinline__ _Float16 f2h(float v) { return (_Float16)fminf(fmaxf(v, -65504.f), 65504.f); }
+__device__ __forceinline__ uint32_t pack2h(float lo, float hi) {
+  typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+  h2 v = {f2h(lo), f2h(hi)};
+  return *reinterpret_cast<uint32_t*>(&v);
+}
+__device__ __forceinline__ U4 pack8h(const float (&f)[8]) {
+  U4 u;
+  u.x = pack2h(f[0], f[1]);
+  u.y = pack2h(f[2], f[3]);
+  u.z = pack2h(f[4], f[5]);
+  u.w = pack2h(f[6], f[7]);
+  return u;
+}
+
 __device__ __forceinline__ U4 pack8(const float (&f)[8]) {
   U4 u;
   u.x = pack2(f[0], f[1]);

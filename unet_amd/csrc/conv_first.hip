@@ -70,8 +70,13 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(int B, int H, int W
       hi[j] = acc[8 + j];
     }
     char* dst = out + (m * o_cs + o_co + q * 16) * 2;
-    *(U4*)dst = pack8(lo);
-    *(U4*)(dst + 16) = pack8(hi);
+    if (mode == UH_EPI_RAW_STATS) {   // BatchNorm input: fp16
+      *(U4*)dst = pack8h(lo);
+      *(U4*)(dst + 16) = pack8h(hi);
+    } else {
+      *(U4*)dst = pack8(lo);
+      *(U4*)(dst + 16) = pack8(hi);
+    }
   }
   if (mode == UH_EPI_RAW_STATS) {
 #pragma unroll

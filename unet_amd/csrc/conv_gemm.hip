@@ -166,7 +166,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmArgs p) {
           s1[j] += v;
           s2[j] += v * v;
         }
-        *(bf16*)(smem + (rbase + e) * C::PITCH + col * 2) = f2bf(v);
+        if (p.mode == UH_EPI_RAW_STATS)
+          *(_Float16*)(smem + (rbase + e) * C::PITCH + col * 2) = f2h(v);   // BatchNorm input: fp16
+        else
+          *(bf16*)(smem + (rbase + e) * C::PITCH + col * 2) = f2bf(v);
       }
     }
   }

@@ -35,21 +35,23 @@ class Act:
         return Act(self.buf, self.B, self.H, self.W, C, self.cstride, coff, self.guard)
 
     # ---- host-side conversions (tests, intermediate_features) ------------------------------
-    def to_nchw(self):
-        """fp32 NCHW copy of the interior."""
+    def to_nchw(self, half=False):
+        """fp32 NCHW copy of the interior (half=True: the rows hold IEEE fp16, not bf16)."""
         B, H, W = self.B, self.H, self.W
-        rows = self.buf[self.guard:self.guard + self.Mp].view(B, H + 1, W + 1, self.cstride)
+        buf = self.buf.view(torch.float16) if half else self.buf
+        rows = buf[self.guard:self.guard + self.Mp].view(B, H + 1, W + 1, self.cstride)
         return rows[:, :H, :W, self.coff:self.coff + self.C].permute(0, 3, 1, 2).float()
 
     def padded_rows(self):
         """[Mp, C] view including pad rows (tests)."""
         return self.buf[self.guard:self.guard + self.Mp, self.coff:self.coff + self.C]
 
-    def fill_from_nchw(self, t):
+    def fill_from_nchw(self, t, half=False):
         B, H, W = self.B, self.H, self.W
-        rows = self.buf[self.guard:self.guard + self.Mp].view(B, H + 1, W + 1, self.cstride)
+        buf = self.buf.view(torch.float16) if half else self.buf
+        rows = buf[self.guard:self.guard + self.Mp].view(B, H + 1, W + 1, self.cstride)
         rows[:, :, :, self.coff:self.coff + self.C] = 0
-        rows[:, :H, :W, self.coff:self.coff + self.C] = t.permute(0, 2, 3, 1).to(torch.bfloat16)
+        rows[:, :H, :W, self.coff:self.coff + self.C] = t.permute(0, 2, 3, 1).to(buf.dtype)
 
 
 def new_act(B, H, W, C, device, cstride=None):
