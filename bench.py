@@ -1,0 +1,144 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: U-Net 3x256x256 training steps (forward + BCE loss + backward +
+gradient all-reduce + Adam) on N MI355X GPUs, one process per GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `value` = images/s over all ranks (weak scaling: 32 images per GPU),
+inputs resident in HBM before the timed region.  `roofline` prices the dominant kernel (the MFMA
+implicit-GEMM convolution: forward, input-gradient and transposed-conv launches) as algorithmic
+FLOPs / event-timed duration against the dense bf16 MFMA peak; `cpu_baseline` is the fp32 CPU oracle
+(oracle/ref_cpu.py, validated against the reference) on a bounded sample on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_DENSE = 2.5e15      # MI355X dense bf16 MFMA, FLOP/s
+BATCH_PER_GPU = 32
+IMG = 256
+FLOP_PER_IMG_FWD_BWD = 288.8e9   # 3 x 96.33 GFLOP forward (2*MAC, all convs) - conv1_1 input gradient, at 256x256
+
+
+def cpu_baseline(threads):
+    """fp32 CPU oracle, fwd + BCE + bwd + Adam, on 4 images of the same 3x256x256 workload."""
+    import torch
+    import torch.nn as nn
+    from oracle import ref_cpu
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    model = ref_cpu.RefUNet(3, 1).train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    x, m = ref_cpu.synth_batch(4, 3, IMG, IMG)
+    crit = nn.BCEWithLogitsLoss()
+    times = []
+    for i in range(4):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        loss = crit(model(x), m)
+        loss.backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    t = sorted(times[1:])[1]                 # median of the 3 timed steps (first is warm-up)
+    return {"value": round(4 / t, 3), "unit": "img/s", "cores": threads, "kind": "port",
+            "sample": "4 images 3x256x256 per step (1/8 of the GPU batch), fp32, 1 warm-up + 3 timed steps, median"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="images per GPU")
+    ap.add_argument("--size", type=int, default=IMG)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import unet_amd
+    from unet_amd.dp import DataParallelTrainer, KernelTimer
+    from oracle import ref_cpu
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    torch.manual_seed(0)
+    model = unet_amd.UNet(3, 1).to(dev)
+    trainer = DataParallelTrainer(model, lr=1e-3)
+    # synthetic data of the ISIC2018 shape, a different shard per rank, resident in HBM
+    x, m = ref_cpu.synth_batch(args.batch, 3, args.size, args.size, seed_img=1234 + rank, seed_mask=4321 + rank)
+    x, m = x.to(dev), m.to(dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.train_step(x, m)
+    barrier()
+    timer = KernelTimer()
+    trainer.timer = timer
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.train_step(x, m)
+    barrier()
+    dt = time.perf_counter() - t0
+    trainer.timer = None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = world * args.batch * args.steps / dt
+        ks = timer.summary()
+        g = ks["conv_gemm"]
+        achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12            # TFLOP/s over all conv_gemm launches
+        scale = (args.size / IMG) ** 2
+        out = {
+            "metric": "train imgs/sec, UNet 256^2 bf16 fwd+bwd, 1/2/4/8 MI355X; % MFMA peak",
+            "value": round(value, 2), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"UNet 3x{args.size}x{args.size}, batch {args.batch}/GPU, BCEWithLogits, "
+                                   "fwd+bwd+grad all-reduce+Adam (BASELINE configs[1])",
+                       "global_batch": world * args.batch, "parallelism": f"dp{world}",
+                       "loss_last_step": round(loss.item(), 6)},
+            "step_mfma_frac": round(value / world * FLOP_PER_IMG_FWD_BWD * scale / PEAK_BF16_DENSE, 4),
+            "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel (conv3x3 fwd + dgrad, convT fwd + dgrad)",
+                         "achieved": round(achieved, 1), "peak": PEAK_BF16_DENSE / 1e12, "unit": "TFLOP/s",
+                         "frac": round(achieved * 1e12 / PEAK_BF16_DENSE, 4), "traffic": None,
+                         "launches_per_step": g["launches"] // args.steps,
+                         "avg_launch_us": round(g["ms"] * 1e3 / g["launches"], 1),
+                         "flop_per_launch": round(g["flops"] / g["launches"] / 1e9, 2)},
+            "kernels": {k: {"TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1),
+                            "ms_per_step": round(v["ms"] / args.steps, 3),
+                            "launches_per_step": v["launches"] // args.steps} for k, v in ks.items()},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(min(16, os.cpu_count() or 1) if "OMP_NUM_THREADS" not in os.environ
+                                               else int(os.environ["OMP_NUM_THREADS"]))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,155 @@
+"""Single-node data-parallel training step for the HIP U-Net: one process per GPU, batches sharded
+across ranks, gradients all-reduced in a few large flat buckets on RCCL while backward is still
+running.
+
+The reference trains on one device (trainer/training_utils.py:32,125-183: Adam, BCEWithLogits or
+clDice loss, per-step loss.item()); this is its multi-GPU counterpart.  Semantics are those of
+DistributedDataParallel: every rank runs the full model on its shard with per-replica BatchNorm
+statistics, the loss is the mean of the per-shard losses, gradients are averaged.
+
+Overlap: the backward pass produces parameter gradients last-layer-first, straight into flat fp32
+buckets laid out in that order.  As soon as the kernels that fill a bucket have been enqueued, its
+all-reduce is issued asynchronously; RCCL runs it on its own stream behind an event, so it overlaps
+with the remaining backward kernels.  xGMI is point-to-point, so buckets are few and large
+(>= 25 MB): per-link bandwidth, not latency, should set the cost.
+"""
+import contextlib
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from .engine import UNetRun
+
+
+class KernelTimer:
+    """Times selected kernel launches with events recorded on the launching stream."""
+
+    def __init__(self):
+        self.records = {}      # tag -> list of (flops, start_event, end_event)
+
+    @contextlib.contextmanager
+    def launch(self, tag, flops):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        yield
+        e1.record()
+        self.records.setdefault(tag, []).append((flops, e0, e1))
+
+    def summary(self):
+        """tag -> dict(launches, flops, ms); call after torch.cuda.synchronize()."""
+        out = {}
+        for tag, recs in self.records.items():
+            ms = sum(e0.elapsed_time(e1) for _, e0, e1 in recs)
+            out[tag] = dict(launches=len(recs), flops=sum(f for f, _, _ in recs), ms=ms)
+        return out
+
+
+def backward_param_order(model):
+    """Parameter names in the order the backward pass produces their gradients."""
+    order = ["final_conv.weight", "final_conv.bias"]
+
+    def layer(conv):
+        bn = conv.replace("conv", "bn", 1)
+        return [bn + ".weight", bn + ".bias", conv + ".weight", conv + ".bias"]
+
+    for k in (4, 3, 2, 1):
+        order += layer(f"conv_up{k}_2") + layer(f"conv_up{k}_1") + [f"upconv{k}.weight", f"upconv{k}.bias"]
+    for l in (5, 4, 3, 2, 1):
+        order += layer(f"conv{l}_2") + layer(f"conv{l}_1")
+    names = {n for n, _ in model.named_parameters()}
+    assert set(order) == names, (set(order) ^ names)
+    return order
+
+
+class GradBuckets:
+    """Flat fp32 gradient storage in backward order, cut into buckets of >= bucket_bytes."""
+
+    def __init__(self, model, bucket_bytes=25 << 20):
+        params = dict(model.named_parameters())
+        order = backward_param_order(model)
+        dev = next(model.parameters()).device
+        total = sum(params[n].numel() for n in order)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.views, self.bucket_of, self.buckets = {}, {}, []
+        off = start = 0
+        names = []
+        for n in order:
+            p = params[n]
+            self.views[n] = self.flat[off:off + p.numel()].view(p.shape)
+            names.append(n)
+            off += p.numel()
+            if (off - start) * 4 >= bucket_bytes:
+                self._close(start, off, names)
+                start, names = off, []
+        if names:
+            self._close(start, off, names)
+        for n, p in params.items():
+            p.grad = self.views[n]          # the optimizer reads gradients straight from the buckets
+
+    def _close(self, start, end, names):
+        idx = len(self.buckets)
+        self.buckets.append(dict(tensor=self.flat[start:end], names=list(names), pending=set(names)))
+        for n in names:
+            self.bucket_of[n] = idx
+
+    def reset(self):
+        for b in self.buckets:
+            b["pending"] = set(b["names"])
+
+
+class DataParallelTrainer:
+    """fwd + loss + bwd (+ bucketed all-reduce) + Adam for one shard per rank."""
+
+    def __init__(self, model, lr=1e-3, criterion=None, bucket_bytes=25 << 20, process_group=None):
+        self.model = model
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        self.group = process_group
+        self.criterion = criterion if criterion is not None else nn.BCEWithLogitsLoss()
+        self.buckets = GradBuckets(model, bucket_bytes)
+        self.optimizer = torch.optim.Adam(model.parameters(), lr=lr, fused=True)   # training_utils.py:107
+        self.timer = None
+        if self.world > 1:
+            # same initial weights on every rank
+            for p in model.parameters():
+                dist.broadcast(p.data, src=0, group=process_group)
+            for b in model.buffers():
+                dist.broadcast(b.data, src=0, group=process_group)
+
+    @staticmethod
+    def shard(n_items, epoch, rank, world, seed=0):
+        """indices of this rank's shard of a shuffled epoch (same permutation on every rank)."""
+        g = torch.Generator().manual_seed(seed + epoch)
+        perm = torch.randperm(n_items, generator=g)
+        return perm[rank::world]
+
+    def _on_ready(self, names):
+        for n in names:
+            i = self.buckets.bucket_of[n]
+            b = self.buckets.buckets[i]
+            b["pending"].discard(n)
+            if not b["pending"] and self.world > 1 and "work" not in b:
+                b["work"] = dist.all_reduce(b["tensor"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def train_step(self, images, masks, step_optimizer=True):
+        """images [b,C,H,W] fp32, masks [b,1,H,W] on this rank's device.  Returns the local loss (0-dim tensor)."""
+        model = self.model
+        model.train()
+        self.buckets.reset()
+        run = UNetRun(model, images.float().contiguous(), training=True)
+        run.timer = self.timer
+        logits = run.forward().requires_grad_(True)
+        loss = self.criterion(logits, masks)
+        # d(mean over ranks of loss)/dlogits: fold the 1/world of gradient averaging into the seed
+        (dlogits,) = torch.autograd.grad(loss / self.world, logits)
+        run.backward(dlogits, grad_alloc=lambda n, shape: self.buckets.views[n], on_ready=self._on_ready)
+        run.release()
+        for b in self.buckets.buckets:
+            w = b.pop("work", None)
+            if w is not None:
+                w.wait()                     # current stream waits for the collective
+        if step_optimizer:
+            self.optimizer.step()
+        return loss.detach()

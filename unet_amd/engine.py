@@ -50,8 +50,25 @@ class UNetRun:
         self.recs = {}
         self.geo = [(B, H >> l, W >> l) for l in range(5)]
         self.masks = [self.pool.rowmask(*g) for g in self.geo]
+        self.grad_alloc = self.on_ready = None
+        self.timer = None          # optional KernelTimer (bench): times selected kernel launches with events
 
     # ------------------------------------------------------------------ helpers
+    def _gemm(self, *args):
+        """uh_conv_gemm; with a KernelTimer attached, bracketed by events on the launching stream."""
+        if self.timer is None:
+            return call("uh_conv_gemm", *args)
+        B, H, W, K, N, T = args[0], args[1], args[2], args[6], args[8], args[9]
+        with self.timer.launch("conv_gemm", 2.0 * B * H * W * K * N * T):
+            call("uh_conv_gemm", *args)
+
+    def _wgrad(self, *args):
+        if self.timer is None:
+            return call("uh_conv_wgrad", *args)
+        B, H, W, N, K, T = args[0], args[1], args[2], args[6], args[10], args[11]
+        with self.timer.launch("conv_wgrad", 2.0 * B * H * W * K * N * T):
+            call("uh_conv_wgrad", *args)
+
     def _pack(self, w, N, T, K, sn, st, sk, on, ot, reverse=0):
         dst = self.lease.bf16_flat(N * T * K)
         call("uh_pack_weights", w.data_ptr(), dst.data_ptr(), N, T, K, sn, st, sk, on, ot, reverse, _stream())
@@ -96,7 +113,7 @@ class UNetRun:
                 wp = self._pack(conv.weight, cout, 9, cin, cin * 9, 1, 9, 9 * cin, cin)
                 parts = _lib.lib.uh_conv_gemm_mtiles(B, H, W, cout)
                 stat = self.lease.f32(parts * 2 * cout)
-                call("uh_conv_gemm", B, H, W, a_in.ptr, a_in.cstride, a_in.coff, cin, wp.data_ptr(), cout, 9,
+                self._gemm(B, H, W, a_in.ptr, a_in.cstride, a_in.coff, cin, wp.data_ptr(), cout, 9,
                      EPI_RAW_STATS, rec.y.ptr, rec.y.cstride, rec.y.coff, conv.bias.data_ptr(), None, None,
                      stat.data_ptr(), self.masks[lvl].data_ptr(), s)
             self._finish_bn(rec, lvl, stat, parts, conv, bn)
@@ -112,7 +129,7 @@ class UNetRun:
                      a_out.cstride, a_out.coff, None, s)
             else:
                 wp = self._pack(conv.weight, cout, 9, cin, cin * 9, 1, 9, 9 * cin, cin)
-                call("uh_conv_gemm", B, H, W, a_in.ptr, a_in.cstride, a_in.coff, cin, wp.data_ptr(), cout, 9,
+                self._gemm(B, H, W, a_in.ptr, a_in.cstride, a_in.coff, cin, wp.data_ptr(), cout, 9,
                      EPI_AFFINE_RELU, a_out.ptr, a_out.cstride, a_out.coff, None, scale.data_ptr(),
                      shift.data_ptr(), None, self.masks[lvl].data_ptr(), s)
         return a_out
@@ -149,7 +166,7 @@ class UNetRun:
             # W[ci][co][a][b] -> GEMM rows n = (a*2+b)*Cout + co
             wp = self._pack(up.weight, w, 4, 2 * w, 4, 1, w * 4, 2 * w, w * 2 * w)
             dst = cat[l].window(w, w)
-            call("uh_conv_gemm", Bs, Hs, Ws, cur.ptr, cur.cstride, cur.coff, 2 * w, wp.data_ptr(), 4 * w, 1,
+            self._gemm(Bs, Hs, Ws, cur.ptr, cur.cstride, cur.coff, 2 * w, wp.data_ptr(), 4 * w, 1,
                  EPI_CONVT, dst.ptr, dst.cstride, dst.coff, up.bias.data_ptr(), None, None, None,
                  self.masks[l + 1].data_ptr(), s)
             acts[f"upconv{k}_in"] = cur
@@ -170,6 +187,21 @@ class UNetRun:
         return logits
 
     # ------------------------------------------------------------------ backward
+    def _galloc(self, name, shape, zero=False):
+        """Gradient tensor for parameter `name`: from the caller's allocator (flat all-reduce buckets
+        in data-parallel training) or a fresh tensor."""
+        if self.grad_alloc is not None:
+            t = self.grad_alloc(name, shape)
+            if zero:
+                t.zero_()
+            return t
+        f = torch.zeros if zero else torch.empty
+        return f(shape, dtype=torch.float32, device=self.device)
+
+    def _ready(self, *names):
+        if self.on_ready is not None:
+            self.on_ready(names)
+
     def _cbr_backward(self, name, lvl, da, grads, want_dgrad=True):
         """Backward of conv3x3+BN+ReLU.  `da` = gradient w.r.t. the layer's activated output.
         Returns the gradient w.r.t. the layer's input activation (an Act with a_in's channel count)."""
@@ -180,14 +212,14 @@ class UNetRun:
         C, cin = rec.cout, rec.cin
         y = rec.y
         Mp = y.Mp
+        bnname = name.replace("conv", "bn", 1)
         parts = _lib.lib.uh_bn_bwd_parts(Mp, C)
         partial = L.f32(parts * 2 * C)
         call("uh_bn_relu_bwd_reduce", Mp, C, da.ptr, da.cstride, da.coff, y.ptr, y.cstride, y.coff,
              rec.mean.data_ptr(), rec.invstd.data_ptr(), rec.scale.data_ptr(), rec.shift.data_ptr(),
              partial.data_ptr(), s)
-        bnname = name.replace("conv", "bn", 1)
-        dgamma = torch.empty(C, dtype=torch.float32, device=self.device)
-        dbeta = torch.empty(C, dtype=torch.float32, device=self.device)
+        dgamma = self._galloc(bnname + ".weight", (C,))
+        dbeta = self._galloc(bnname + ".bias", (C,))
         coef = L.f32(2 * C)
         call("uh_bn_bwd_finalize", partial.data_ptr(), parts, C, B * H * W, dgamma.data_ptr(), dbeta.data_ptr(),
              coef.data_ptr(), 0, s)
@@ -198,8 +230,9 @@ class UNetRun:
              coef.data_ptr(), self.masks[lvl].data_ptr(), dy.ptr, dy.cstride, dy.coff, s)
         # the bias of a conv that feeds train-mode BatchNorm has an exactly zero gradient:
         # BN subtracts the batch mean, so sum_m dy[m][c] == 0 for every channel.
-        grads[name + ".bias"] = torch.zeros(C, dtype=torch.float32, device=self.device)
-        dw = torch.empty_like(conv.weight)
+        grads[name + ".bias"] = self._galloc(name + ".bias", (C,), zero=True)
+        dw = self._galloc(name + ".weight", tuple(conv.weight.shape))
+        done = (bnname + ".weight", bnname + ".bias", name + ".weight", name + ".bias")
         if rec.a_in is None:
             parts = _lib.lib.uh_conv_first_wgrad_parts(B, H, W)
             wpart = L.f32(parts * C * cin * 9)
@@ -208,26 +241,33 @@ class UNetRun:
             call("uh_wgrad_reduce", wpart.data_ptr(), parts, C, 1, cin * 9, cin * 9, 0, cin * 9, 0, 1,
                  dw.data_ptr(), 0, s)
             grads[name + ".weight"] = dw
+            self._ready(*done)
             return None
         a_in = rec.a_in
         S = _lib.lib.uh_conv_wgrad_splits(B, H, W, C, cin, 9)
         wpart = L.f32(S * C * 9 * cin)
-        call("uh_conv_wgrad", B, H, W, dy.ptr, dy.cstride, dy.coff, C, a_in.ptr, a_in.cstride, a_in.coff, cin, 9,
+        self._wgrad(B, H, W, dy.ptr, dy.cstride, dy.coff, C, a_in.ptr, a_in.cstride, a_in.coff, cin, 9,
              wpart.data_ptr(), s)
         # partial [n][t][k] -> OIHW: grad[n*cin*9 + k*9 + t]
         call("uh_wgrad_reduce", wpart.data_ptr(), S, C, 9, cin, 9 * cin, cin, cin * 9, 1, 9, dw.data_ptr(), 0, s)
         grads[name + ".weight"] = dw
+        self._ready(*done)
         if not want_dgrad:
             return None
         # dgrad: dx[m][ci] = sum_t sum_co dy[m + off(t)][co] * W[co][ci][8-t]
         wd = self._pack(conv.weight, cin, 9, C, 9, 1, cin * 9, 9 * C, C, reverse=1)
         dx = L.act(B, H, W, cin)
-        call("uh_conv_gemm", B, H, W, dy.ptr, dy.cstride, dy.coff, C, wd.data_ptr(), cin, 9, EPI_MASKED,
+        self._gemm(B, H, W, dy.ptr, dy.cstride, dy.coff, C, wd.data_ptr(), cin, 9, EPI_MASKED,
              dx.ptr, dx.cstride, dx.coff, None, None, None, None, self.masks[lvl].data_ptr(), s)
         return dx
 
-    def backward(self, dlogits):
-        """Returns {parameter name: fp32 gradient} for every parameter of the module."""
+    def backward(self, dlogits, grad_alloc=None, on_ready=None):
+        """Returns {parameter name: fp32 gradient} for every parameter of the module.
+
+        grad_alloc(name, shape) -> tensor lets the caller place gradients (e.g. inside flat all-reduce
+        buckets); on_ready(names) is called as soon as the kernels producing those gradients have been
+        enqueued on the current stream, in backward order (head first, conv1_1 last)."""
+        self.grad_alloc, self.on_ready = grad_alloc, on_ready
         if not self.training:
             raise RuntimeError("backward through an eval-mode (running-statistics) forward is not built; "
                                "call model.train() before a forward pass that needs gradients")
@@ -243,11 +283,14 @@ class UNetRun:
         hp = L.f32(parts * oc * 65)
         call("uh_head_bwd", B, H, W, 64, oc, a.ptr, a.cstride, a.coff, fc.weight.data_ptr(), dl.data_ptr(),
              da.ptr, da.cstride, da.coff, hp.data_ptr(), s)
-        hw = torch.empty(oc * 65, dtype=torch.float32, device=self.device)
+        hw = L.f32(oc * 65)
         call("uh_colsum_finalize", hp.data_ptr(), parts, oc * 65, 1, hw.data_ptr(), 0, s)
         hw = hw.view(oc, 65)
-        grads["final_conv.weight"] = hw[:, :64].reshape(oc, 64, 1, 1).contiguous()
-        grads["final_conv.bias"] = hw[:, 64].contiguous()
+        gw, gb = self._galloc("final_conv.weight", (oc, 64, 1, 1)), self._galloc("final_conv.bias", (oc,))
+        gw.copy_(hw[:, :64].reshape(oc, 64, 1, 1))
+        gb.copy_(hw[:, 64])
+        grads["final_conv.weight"], grads["final_conv.bias"] = gw, gb
+        self._ready("final_conv.weight", "final_conv.bias")
 
         skip_grads = [None] * 4
         for k in range(4, 0, -1):                            # decoder, last stage first
@@ -263,7 +306,7 @@ class UNetRun:
             parts = _lib.lib.uh_colsum_parts(dup.Mp, w)
             cp = L.f32(parts * w)
             call("uh_colsum", dup.Mp, w, dup.ptr, dup.cstride, dup.coff, cp.data_ptr(), s)
-            db = torch.empty(w, dtype=torch.float32, device=self.device)
+            db = self._galloc(f"upconv{k}.bias", (w,))
             call("uh_colsum_finalize", cp.data_ptr(), parts, w, 1, db.data_ptr(), 0, s)
             grads[f"upconv{k}.bias"] = db
             # gather the 2x2 output positions of every input position: d4[m][t*w + co]
@@ -274,15 +317,16 @@ class UNetRun:
             cin = 2 * w
             S = _lib.lib.uh_conv_wgrad_splits(Bs, Hs, Ws, 4 * w, cin, 1)
             wpart = L.f32(S * 4 * w * cin)
-            call("uh_conv_wgrad", Bs, Hs, Ws, d4.ptr, d4.cstride, d4.coff, 4 * w, a_in.ptr, a_in.cstride, a_in.coff,
+            self._wgrad(Bs, Hs, Ws, d4.ptr, d4.cstride, d4.coff, 4 * w, a_in.ptr, a_in.cstride, a_in.coff,
                  cin, 1, wpart.data_ptr(), s)
-            dw = torch.empty_like(up.weight)                 # [cin][w][2][2]
+            dw = self._galloc(f"upconv{k}.weight", tuple(up.weight.shape))     # [cin][w][2][2]
             call("uh_wgrad_reduce", wpart.data_ptr(), S, w, 4, cin, cin, w * cin, 4, 1, w * 4, dw.data_ptr(), 0, s)
             grads[f"upconv{k}.weight"] = dw
+            self._ready(f"upconv{k}.weight", f"upconv{k}.bias")
             # input gradient: dx[m][ci] = sum_{t,co} d4[m][t*w+co] * W[ci][co][t]
             wd = self._pack(up.weight, cin, 4, w, w * 4, 1, 4, 4 * w, w)
             da = L.act(Bs, Hs, Ws, cin)
-            call("uh_conv_gemm", Bs, Hs, Ws, d4.ptr, d4.cstride, d4.coff, 4 * w, wd.data_ptr(), cin, 1, EPI_MASKED,
+            self._gemm(Bs, Hs, Ws, d4.ptr, d4.cstride, d4.coff, 4 * w, wd.data_ptr(), cin, 1, EPI_MASKED,
                  da.ptr, da.cstride, da.coff, None, None, None, None, self.masks[l + 1].data_ptr(), s)
         for l in range(4, -1, -1):                           # bridge, then encoder levels 3..0
             w = WIDTHS[l]
