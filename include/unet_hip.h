@@ -150,6 +150,28 @@ int uh_head_bwd(int B, int H, int W, int C, int OC, const void* a, int a_cstride
                 const float* w, const float* dlogits_nchw,
                 void* da, int da_cstride, int da_coff, float* partial /*[P][OC][C+1]*/, uh_stream s);
 
+/* ---- clDice soft-skeleton loss, fp32 planes [planes][H][W] (losses/cl_dice.py) ---------------------
+ * soft_erode (cl_dice.py:12-17): 5-point-cross minimum, out-of-image neighbours ignored; clamp != 0 first
+ * clamps the input to [0,1] (cl_dice.py:116-117).  soft_dilate (cl_dice.py:24-27): 3x3 maximum. */
+int uh_soft_erode(int planes, int H, int W, const float* in, float* out, int clamp, uh_stream s);
+int uh_soft_dilate(int planes, int H, int W, const float* in, float* out, uh_stream s);
+/* soft_skel with num_iter = 10 (cl_dice.py:35-46,103) of clamp(x,0,1); workspace = 3 planesets */
+size_t uh_soft_skel_workspace(int planes, int H, int W);
+int uh_soft_skel(int planes, int H, int W, const float* x, float* skel, float* workspace, uh_stream s);
+/* soft_dice_cldice.forward(y_true, y_pred) (cl_dice.py:106-125): loss_out[0] = (1-alpha)*dice + alpha*clDice.
+ * The workspace (uh_cldice_workspace bytes) keeps what backward needs: the eleven erosion levels and
+ * skeleton states of y_pred, skel(y_true), and the scalar coefficients. */
+size_t uh_cldice_workspace(int planes, int H, int W);
+int uh_cldice_forward(int planes, int H, int W, const float* y_true, const float* y_pred,
+                      float alpha, float smooth, float* workspace, float* loss_out, uh_stream s);
+/* grad_pred = grad_out[0] * dLoss/dy_pred, with autograd's tie rules (first extremum of a pooling window,
+ * 1/2:1/2 split in min(), relu'(0)=0, clamp passes the gradient on [0,1]).  Uses the forward's workspace. */
+int uh_cldice_backward(int planes, int H, int W, const float* y_true, const float* y_pred,
+                       float* workspace, const float* grad_out, float* grad_pred, uh_stream s);
+/* out17 = loss, 5 gradient coefficients, dice, clDice, tprec, tsens, then the seven global sums
+ * (sum t*p, sum t, sum p, sum skel_p*t, sum skel_p, sum skel_t*p, sum skel_t) */
+int uh_cldice_read_terms(const float* workspace, int planes, int H, int W, float* out17, uh_stream s);
+
 #ifdef __cplusplus
 }
 #endif

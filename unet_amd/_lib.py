@@ -49,6 +49,14 @@ SIGNATURES = {
     "uh_head_fwd": (I, [I, I, I, I, I, P, I, I, P, P, P, P]),
     "uh_head_bwd_parts": (I, [I, I, I]),
     "uh_head_bwd": (I, [I, I, I, I, I, P, I, I, P, P, P, I, I, P, P]),
+    "uh_soft_erode": (I, [I, I, I, P, P, I, P]),
+    "uh_soft_dilate": (I, [I, I, I, P, P, P]),
+    "uh_soft_skel_workspace": (Z, [I, I, I]),
+    "uh_soft_skel": (I, [I, I, I, P, P, P, P]),
+    "uh_cldice_workspace": (Z, [I, I, I]),
+    "uh_cldice_forward": (I, [I, I, I, P, P, F, F, P, P, P]),
+    "uh_cldice_backward": (I, [I, I, I, P, P, P, P, P, P]),
+    "uh_cldice_read_terms": (I, [P, I, I, I, P, P]),
 }
 
 EPI_RAW_STATS, EPI_AFFINE_RELU, EPI_MASKED, EPI_CONVT = 0, 1, 2, 3

@@ -1,0 +1,134 @@
+"""Drop-in clDice loss: `soft_dice_cldice`, `soft_cldice`, `soft_dice`, `SoftSkeletonize` with the
+reference's names, constructor arguments and call convention (losses/cl_dice.py), computed by the HIP
+kernels of libunet_hip.so in fp32.  Call as the trainer does (training_utils.py:146-148):
+
+    probs = torch.sigmoid(logits).clamp(1e-6, 1 - 1e-6)
+    loss = criterion(masks, probs)            # argument order (y_true, y_pred)
+"""
+import torch
+import torch.nn as nn
+
+from ._lib import call, lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _planes(t, what):
+    if t.dim() == 5:
+        raise NotImplementedError("the 3-D (5-D tensor) branch of the soft skeleton is not built")
+    if t.dim() != 4:
+        raise ValueError(f"{what}: expected [B,C,H,W], got {tuple(t.shape)}")
+    if not t.is_cuda:
+        raise RuntimeError("unet_amd clDice runs on the HIP kernels only: tensors must be on a ROCm device")
+    return t.shape[0] * t.shape[1], t.shape[2], t.shape[3]
+
+
+class _ClDiceFn(torch.autograd.Function):
+    """forward(y_true, y_pred, alpha, smooth, mode) -> 0-dim loss.  mode 0: (1-alpha)*dice + alpha*clDice,
+    mode 1: clDice only (soft_cldice), mode 2: dice only (soft_dice)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, y_true, y_pred, alpha, smooth):
+        planes, H, W = _planes(y_pred, "y_pred")
+        if y_true.shape != y_pred.shape:
+            raise ValueError(f"y_true {tuple(y_true.shape)} and y_pred {tuple(y_pred.shape)} differ")
+        yt = y_true.detach().float().contiguous()
+        yp = y_pred.detach().float().contiguous()
+        ws = torch.empty(lib.uh_cldice_workspace(planes, H, W) // 4, dtype=torch.float32, device=yp.device)
+        loss = torch.empty((), dtype=torch.float32, device=yp.device)
+        call("uh_cldice_forward", planes, H, W, yt.data_ptr(), yp.data_ptr(), float(alpha), float(smooth),
+             ws.data_ptr(), loss.data_ptr(), _stream())
+        ctx.save_for_backward(yt, yp, ws)
+        ctx.dims = (planes, H, W)
+        return loss
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, gout):
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError("gradient with respect to y_true is not built")
+        yt, yp, ws = ctx.saved_tensors
+        planes, H, W = ctx.dims
+        g = gout.detach().float().contiguous()
+        grad = torch.empty_like(yp)
+        call("uh_cldice_backward", planes, H, W, yt.data_ptr(), yp.data_ptr(), ws.data_ptr(), g.data_ptr(),
+             grad.data_ptr(), _stream())
+        return None, grad, None, None
+
+
+class SoftSkeletonize(nn.Module):
+    """cl_dice.py:5-50.  The HIP kernel is built for num_iter = 10, the only value the reference instantiates
+    (cl_dice.py:57,103); forward only (the differentiable path is soft_dice_cldice / soft_cldice)."""
+
+    def __init__(self, num_iter=40):
+        super().__init__()
+        self.num_iter = num_iter
+
+    def _morph(self, img, which):
+        planes, H, W = _planes(img, "img")
+        x = img.detach().float().contiguous()
+        out = torch.empty_like(x)
+        if which == "erode":
+            call("uh_soft_erode", planes, H, W, x.data_ptr(), out.data_ptr(), 0, _stream())
+        else:
+            call("uh_soft_dilate", planes, H, W, x.data_ptr(), out.data_ptr(), _stream())
+        return out
+
+    def soft_erode(self, img):
+        return self._morph(img, "erode")
+
+    def soft_dilate(self, img):
+        return self._morph(img, "dilate")
+
+    def soft_open(self, img):
+        return self.soft_dilate(self.soft_erode(img))
+
+    def soft_skel(self, img):
+        if self.num_iter != 10:
+            raise NotImplementedError("the soft-skeleton kernel is built for num_iter=10")
+        planes, H, W = _planes(img, "img")
+        x = img.detach().float().contiguous()
+        if x.numel() and (x.min() < 0 or x.max() > 1):
+            raise NotImplementedError("the soft-skeleton kernel takes inputs in [0,1] (it clamps, as the loss does)")
+        out = torch.empty_like(x)
+        ws = torch.empty(lib.uh_soft_skel_workspace(planes, H, W) // 4, dtype=torch.float32, device=x.device)
+        call("uh_soft_skel", planes, H, W, x.data_ptr(), out.data_ptr(), ws.data_ptr(), _stream())
+        return out
+
+    def forward(self, img):
+        return self.soft_skel(img)
+
+
+class soft_dice_cldice(nn.Module):
+    """cl_dice.py:97-125: (1-alpha)*soft_dice + alpha*clDice, ten skeleton iterations (iter_ is ignored there too)."""
+
+    def __init__(self, iter_=3, alpha=0.5, smooth=1., exclude_background=False):
+        super().__init__()
+        self.iter, self.smooth, self.alpha = iter_, smooth, alpha
+        self.soft_skeletonize = SoftSkeletonize(num_iter=10)
+        self.exclude_background = exclude_background     # a no-op slice in the reference (cl_dice.py:107-109)
+
+    def forward(self, y_true, y_pred):
+        return _ClDiceFn.apply(y_true, y_pred, self.alpha, self.smooth)
+
+
+class soft_cldice(nn.Module):
+    """cl_dice.py:52-70: clDice term only; unlike soft_dice_cldice it does not clamp its inputs, so they must
+    already lie in [0,1] (the kernel clamps, which is then the identity)."""
+
+    def __init__(self, iter_=3, smooth=1., exclude_background=False):
+        super().__init__()
+        self.iter, self.smooth = iter_, smooth
+        self.soft_skeletonize = SoftSkeletonize(num_iter=10)
+        self.exclude_background = exclude_background
+
+    def forward(self, y_true, y_pred):
+        return _ClDiceFn.apply(y_true, y_pred, 1.0, self.smooth)
+
+
+def soft_dice(y_true, y_pred):
+    """cl_dice.py:73-94 (dice term only)."""
+    return _ClDiceFn.apply(y_true, y_pred, 0.0, 1.0)

@@ -1,0 +1,463 @@
+// clDice soft-skeleton loss (losses/cl_dice.py of the reference) on gfx950: fp32, bandwidth bound.
+//
+// The reference iterates   img <- erode(img); delta = relu(img - dilate(erode(img))); skel += relu(delta - skel*delta)
+// ten times.  With E_0 = clamp(x,0,1) and E_{k+1} = erode(E_k) the same values are
+//     delta_k = relu(E_k - dilate(E_{k+1})),  skel_0 = delta_0,  skel_k = skel_{k-1} + relu(delta_k - skel_{k-1}*delta_k)
+// for k = 0..10, i.e. ONE chain of eleven erosions instead of twenty-one (the reference erodes every level twice,
+// once inside soft_open and once at the top of the next iteration; both give the same tensor and their gradients add).
+// erode  = 5-point-cross minimum, out-of-image neighbours ignored (cl_dice.py:15-17),
+// dilate = 3x3 maximum, out-of-image neighbours ignored            (cl_dice.py:27).
+//
+// Forward: one launch per level k reads E_k (centre), the 3x3 neighbourhood of E_{k+1} and skel_{k-1}, and writes
+// skel_k and E_{k+2}.  Backward: one launch per level, 32x32 tiles with halos staged in LDS, three in-tile stages
+// (pointwise masks -> dilation scatter turned into a gather -> erosion routing), reproducing autograd's tie rules:
+// max-pool sends the gradient to the FIRST extremum in row-major window order, torch.min splits ties 1/2:1/2,
+// relu'(0) = 0, clamp passes the gradient on its closed interval.
+// All sums are two-stage (per-workgroup partials, then one finalising workgroup): deterministic, no atomics.
+#include "common.h"
+#pragma clang fp contract(off)   // keep delta - skel*delta as two roundings, like the reference's separate ops
+
+#define SKEL_LEVELS 11            // E_1..E_11, skel_0..skel_10  (num_iter = 10, cl_dice.py:103)
+
+struct Img {
+  int H, W;
+  __device__ __forceinline__ bool in(int y, int x) const { return y >= 0 && y < H && x >= 0 && x < W; }
+};
+
+__device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.f), 1.f); }
+
+// 5-point-cross minimum at (y,x) of plane p; CLAMP: the plane holds raw input and E_0 = clamp01(input)
+template <bool CLAMP>
+__device__ __forceinline__ float erode_at(const float* __restrict__ p, Img g, int y, int x) {
+  float v = p[y * g.W + x];
+  if (y > 0) v = fminf(v, p[(y - 1) * g.W + x]);
+  if (y + 1 < g.H) v = fminf(v, p[(y + 1) * g.W + x]);
+  if (x > 0) v = fminf(v, p[y * g.W + x - 1]);
+  if (x + 1 < g.W) v = fminf(v, p[y * g.W + x + 1]);
+  return CLAMP ? clamp01(v) : v;   // clamp is monotone: min(clamp(.)) == clamp(min(.))
+}
+
+__device__ __forceinline__ float dilate_at(const float* __restrict__ p, Img g, int y, int x) {
+  float v = -INFINITY;
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx)
+      if (g.in(y + dy, x + dx)) v = fmaxf(v, p[(y + dy) * g.W + x + dx]);
+  return v;
+}
+
+// ---- stand-alone morphology (also the first erosion of every chain) -----------------------------------
+template <bool CLAMP, bool DILATE>
+__global__ __launch_bounds__(256) void morph_kernel(int planes, int H, int W, const float* __restrict__ in,
+                                                    float* __restrict__ out) {
+  const Img g{H, W};
+  const long long n = (long long)planes * H * W;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int x = (int)(i % W);
+    const long long r = i / W;
+    const int y = (int)(r % H);
+    const float* p = in + (r / H) * H * W;
+    out[i] = DILATE ? dilate_at(p, g, y, x) : erode_at<CLAMP>(p, g, y, x);
+  }
+}
+
+// ---- forward level k ------------------------------------------------------------------------------------
+// skel_k = (k==0) ? delta : skel_prev + relu(delta - skel_prev*delta), delta = relu(E_k - dilate(E_{k+1}));
+// E_{k+2} = erode(E_{k+1}) when ek2 != null.  CLAMP0: ek is the raw input (level 0).
+template <bool CLAMP0>
+__global__ __launch_bounds__(256) void skel_level_kernel(int planes, int H, int W, const float* __restrict__ ek,
+                                                         const float* __restrict__ ek1,
+                                                         const float* __restrict__ skel_prev,
+                                                         float* __restrict__ skel_out, float* __restrict__ ek2) {
+  const Img g{H, W};
+  const long long n = (long long)planes * H * W;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int x = (int)(i % W);
+    const long long r = i / W;
+    const int y = (int)(r % H);
+    const float* p1 = ek1 + (r / H) * H * W;
+    float e = ek[i];
+    if (CLAMP0) e = clamp01(e);
+    const float d = dilate_at(p1, g, y, x);
+    const float delta = fmaxf(e - d, 0.f);
+    float s = delta;
+    if (skel_prev) {
+      const float sp = skel_prev[i];
+      const float prod = sp * delta;
+      s = sp + fmaxf(delta - prod, 0.f);
+    }
+    skel_out[i] = s;
+    if (ek2) ek2[i] = erode_at<false>(p1, g, y, x);
+  }
+}
+
+// ---- sums ---------------------------------------------------------------------------------------------------
+// partial[blk][7] = (sum t*p, sum t, sum p, sum skel_p*t, sum skel_p, sum skel_t*p, sum skel_t), t,p clamped
+__global__ __launch_bounds__(256) void cldice_sums_kernel(long long n, const float* __restrict__ yt,
+                                                          const float* __restrict__ yp,
+                                                          const float* __restrict__ skp,
+                                                          const float* __restrict__ skt, float* __restrict__ partial) {
+  float s[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float t = clamp01(yt[i]), p = clamp01(yp[i]);
+    const float a = skp[i], b = skt[i];
+    s[0] += t * p;
+    s[1] += t;
+    s[2] += p;
+    s[3] += a * t;
+    s[4] += a;
+    s[5] += b * p;
+    s[6] += b;
+  }
+  __shared__ float red[4][7];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    const float v = wave_sum(s[k]);
+    if (lane == 0) red[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 7)
+    partial[blockIdx.x * 7 + threadIdx.x] =
+        red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// coef: [0] loss, [1..3] direct gradient dL/dp = c1*t + c2 + c3*skel_t, [4..5] g_skel_pred = c4*t + c5,
+//       [6] dice, [7] cl_dice, [8] tprec, [9] tsens, [10..16] the seven sums
+__global__ __launch_bounds__(256) void cldice_finalize_kernel(const float* __restrict__ partial, int P, float alpha,
+                                                              float smooth, float* __restrict__ coef) {
+  __shared__ double red[256][7];
+  double s[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (int p = threadIdx.x; p < P; p += 256)
+#pragma unroll
+    for (int k = 0; k < 7; ++k) s[k] += (double)partial[p * 7 + k];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) red[threadIdx.x][k] = s[k];
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (threadIdx.x < st)
+#pragma unroll
+      for (int k = 0; k < 7; ++k) red[threadIdx.x][k] += red[threadIdx.x + st][k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double I = red[0][0], St = red[0][1], Sp = red[0][2], A = red[0][3], Ssp = red[0][4], Bv = red[0][5],
+                 Sst = red[0][6];
+    const double den = St + Sp + 1.0, num = 2.0 * I + 1.0;     // soft_dice hard-codes smooth = 1 (cl_dice.py:83)
+    const double dice = 1.0 - num / den;
+    const double tprec = (A + smooth) / (Ssp + smooth), tsens = (Bv + smooth) / (Sst + smooth);
+    const double cl = 1.0 - 2.0 * tprec * tsens / (tprec + tsens);
+    const double dcl_dprec = -2.0 * tsens * tsens / ((tprec + tsens) * (tprec + tsens));
+    const double dcl_dsens = -2.0 * tprec * tprec / ((tprec + tsens) * (tprec + tsens));
+    coef[0] = (float)((1.0 - alpha) * dice + alpha * cl);
+    coef[1] = (float)(-(1.0 - alpha) * 2.0 / den);
+    coef[2] = (float)((1.0 - alpha) * num / (den * den));
+    coef[3] = (float)(alpha * dcl_dsens / (Sst + smooth));
+    coef[4] = (float)(alpha * dcl_dprec / (Ssp + smooth));
+    coef[5] = (float)(-alpha * dcl_dprec * (A + smooth) / ((Ssp + smooth) * (Ssp + smooth)));
+    coef[6] = (float)dice;
+    coef[7] = (float)cl;
+    coef[8] = (float)tprec;
+    coef[9] = (float)tsens;
+    for (int k = 0; k < 7; ++k) coef[10 + k] = (float)red[0][k];
+  }
+}
+
+// ---- backward level k ------------------------------------------------------------------------------------------
+#define BT 32                       // core tile edge
+struct BwdArgs {
+  const float* ek;                  // E_k (raw input when level0)
+  const float* ek1;                 // E_{k+1}
+  const float* skel_prev;           // skel_{k-1} (null at level 0)
+  const float* gs_in;               // dL/dskel_k (null at the top level: computed from coef and y_true)
+  const float* ge1_in;              // dL/dE_{k+1} without the dilation term of this level (null at the top level)
+  float* gs_out;                    // dL/dskel_{k-1} (null at level 0)
+  float* ge_out;                    // dL/dE_k without the dilation term of level k-1; at level 0: dL/dy_pred
+  const float* yt;                  // y_true (top level and level 0)
+  const float* skt;                 // skel_true (level 0)
+  const float* coef;
+  const float* gout;                // upstream gradient (scalar on the device)
+  int H, W, level0, top;
+};
+
+__global__ __launch_bounds__(256) void skel_bwd_level_kernel(BwdArgs a) {
+  constexpr int N3 = BT + 6, N2 = BT + 4, N1 = BT + 2;
+  __shared__ float sE1[N3 * N3];    // E_{k+1}, halo 3
+  __shared__ float sE[N2 * N2];     // E_k, halo 2
+  __shared__ float sGD[N2 * N2];    // dL/dD_k, halo 2
+  __shared__ signed char sAM[N2 * N2];  // arg-max slot (0..8) of the 3x3 window of E_{k+1} at each position, halo 2
+  __shared__ float sG1[N1 * N1];    // complete dL/dE_{k+1}, halo 1
+  __shared__ float sDir[BT * BT];   // direct term dL/ddelta_k * mask at the core
+  const Img g{a.H, a.W};
+  const int tid = threadIdx.x;
+  const int x0 = blockIdx.x * BT, y0 = blockIdx.y * BT;
+  const long long plane = (long long)blockIdx.z * a.H * a.W;
+  const float* ek = a.ek + plane;
+  const float* ek1 = a.ek1 + plane;
+  const float gout = *a.gout;
+
+  for (int i = tid; i < N3 * N3; i += 256) {
+    const int y = y0 - 3 + i / N3, x = x0 - 3 + i % N3;
+    sE1[i] = g.in(y, x) ? ek1[y * a.W + x] : 0.f;
+  }
+  for (int i = tid; i < N2 * N2; i += 256) {
+    const int y = y0 - 2 + i / N2, x = x0 - 2 + i % N2;
+    float v = 0.f;
+    if (g.in(y, x)) {
+      v = ek[y * a.W + x];
+      if (a.level0) v = clamp01(v);
+    }
+    sE[i] = v;
+  }
+  __syncthreads();
+
+  // stage A: pointwise on core+2
+  for (int i = tid; i < N2 * N2; i += 256) {
+    const int ly = i / N2, lx = i % N2;
+    const int y = y0 - 2 + ly, x = x0 - 2 + lx;
+    float gd = 0.f;
+    int am = -1;
+    if (g.in(y, x)) {
+      // 3x3 window of E_{k+1} in row-major order, first maximum wins
+      float best = -INFINITY;
+#pragma unroll
+      for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+          if (!g.in(y + dy, x + dx)) continue;
+          const float v = sE1[(ly + 1 + dy) * N3 + lx + 1 + dx];
+          if (v > best) {
+            best = v;
+            am = (dy + 1) * 3 + dx + 1;
+          }
+        }
+      const float e = sE[i];
+      const float diff = e - best;
+      const float delta = fmaxf(diff, 0.f);
+      const long long gi = plane + (long long)y * a.W + x;
+      float gs;
+      if (a.top) {
+        gs = gout * (a.coef[4] * clamp01(a.yt[gi]) + a.coef[5]);
+      } else {
+        gs = a.gs_in[gi];
+      }
+      float gdelta = gs;
+      if (a.skel_prev) {
+        const float sp = a.skel_prev[gi];
+        const float prod = sp * delta;
+        const bool on = (delta - prod) > 0.f;
+        gdelta = on ? gs * (1.f - sp) : 0.f;
+        const bool core = (ly >= 2 && ly < 2 + BT && lx >= 2 && lx < 2 + BT);
+        if (core) a.gs_out[gi] = on ? gs * (1.f - delta) : gs;
+      }
+      const float dmask = diff > 0.f ? gdelta : 0.f;
+      gd = -dmask;
+      if (ly >= 2 && ly < 2 + BT && lx >= 2 && lx < 2 + BT) sDir[(ly - 2) * BT + lx - 2] = dmask;
+    }
+    sGD[i] = gd;
+    sAM[i] = (signed char)am;
+  }
+  __syncthreads();
+
+  // stage B: complete dL/dE_{k+1} on core+1 = incoming part + dilation windows whose arg-max is this position
+  for (int i = tid; i < N1 * N1; i += 256) {
+    const int ly = i / N1, lx = i % N1;
+    const int y = y0 - 1 + ly, x = x0 - 1 + lx;
+    float v = 0.f;
+    if (g.in(y, x)) {
+      if (a.ge1_in) v = a.ge1_in[plane + (long long)y * a.W + x];
+#pragma unroll
+      for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+          // window centred at q = p + (dy,dx); p sits at slot (-dy+1)*3 + (-dx+1) of that window
+          const int qi = (ly + 1 + dy) * N2 + lx + 1 + dx;
+          if (sAM[qi] == (1 - dy) * 3 + (1 - dx)) v += sGD[qi];
+        }
+    }
+    sG1[i] = v;
+  }
+  __syncthreads();
+
+  // stage C: route dL/dE_{k+1} through E_{k+1} = erode(E_k) back to E_k at the core
+  for (int i = tid; i < BT * BT; i += 256) {
+    const int cy = i / BT, cx = i % BT;
+    const int y = y0 + cy, x = x0 + cx;
+    if (!g.in(y, x)) continue;
+    float acc = sDir[i];
+    // the five erosion windows that contain p: centred at p, p+-row, p+-col
+    const int qdy[5] = {0, -1, 1, 0, 0}, qdx[5] = {0, 0, 0, -1, 1};
+#pragma unroll
+    for (int w = 0; w < 5; ++w) {
+      const int qy = y + qdy[w], qx = x + qdx[w];
+      if (!g.in(qy, qx)) continue;
+      const int ly = cy + 2 + qdy[w], lx = cx + 2 + qdx[w];      // q in sE coordinates
+      const float gq = sG1[(cy + 1 + qdy[w]) * N1 + cx + 1 + qdx[w]];
+      const float c = sE[ly * N2 + lx];
+      // vertical minimum: order top, centre, bottom; first minimum wins
+      float vmin = INFINITY;
+      int varg = 0;
+      if (qy > 0) { vmin = sE[(ly - 1) * N2 + lx]; varg = -1; }
+      if (c < vmin) { vmin = c; varg = 0; }
+      if (qy + 1 < a.H) { const float b = sE[(ly + 1) * N2 + lx]; if (b < vmin) { vmin = b; varg = 1; } }
+      // horizontal minimum: order left, centre, right
+      float hmin = INFINITY;
+      int harg = 0;
+      if (qx > 0) { hmin = sE[ly * N2 + lx - 1]; harg = -1; }
+      if (c < hmin) { hmin = c; harg = 0; }
+      if (qx + 1 < a.W) { const float b = sE[ly * N2 + lx + 1]; if (b < hmin) { hmin = b; harg = 1; } }
+      const float wv = vmin < hmin ? 1.f : (vmin == hmin ? 0.5f : 0.f);
+      const float wh = 1.f - wv;
+      // does the vertical / horizontal arg-min of window q land on p?   p = q - (qdy,qdx)
+      if (qdx[w] == 0 && varg == -qdy[w]) acc += gq * wv;
+      if (qdy[w] == 0 && harg == -qdx[w]) acc += gq * wh;
+    }
+    const long long gi = plane + (long long)y * a.W + x;
+    if (a.level0) {
+      const float raw = ek[y * a.W + x];
+      const float t = clamp01(a.yt[gi]);
+      const float direct = gout * (a.coef[1] * t + a.coef[2] + a.coef[3] * a.skt[gi]);
+      acc = (raw >= 0.f && raw <= 1.f) ? acc + direct : 0.f;
+    }
+    a.ge_out[gi] = acc;
+  }
+}
+
+// ---- host entry points ----------------------------------------------------------------------------------------
+static int grid_for(long long n) {
+  long long b = (n + 255) / 256;
+  if (b > 4096) b = 4096;
+  return (int)b;
+}
+
+extern "C" int uh_soft_erode(int planes, int H, int W, const float* in, float* out, int clamp, uh_stream s) {
+  UH_REQUIRE(planes > 0 && H > 0 && W > 0 && in && out, "soft_erode: bad arguments");
+  const long long n = (long long)planes * H * W;
+  if (clamp)
+    hipLaunchKernelGGL((morph_kernel<true, false>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, planes, H, W, in, out);
+  else
+    hipLaunchKernelGGL((morph_kernel<false, false>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, planes, H, W, in, out);
+  return uh_check_launch("soft_erode");
+}
+
+extern "C" int uh_soft_dilate(int planes, int H, int W, const float* in, float* out, uh_stream s) {
+  UH_REQUIRE(planes > 0 && H > 0 && W > 0 && in && out, "soft_dilate: bad arguments");
+  const long long n = (long long)planes * H * W;
+  hipLaunchKernelGGL((morph_kernel<false, true>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, planes, H, W, in, out);
+  return uh_check_launch("soft_dilate");
+}
+
+// E planes: e[0] = input (clamped on the fly), e[k] for k >= 1 at E + (k-1)*n; skel planes at SK + k*n.
+// keep_all = 0: three rotating E buffers and one skeleton plane (E needs 3n floats, SK n floats).
+static int skel_forward(int planes, int H, int W, const float* x, float* E, float* SK, int keep_all, hipStream_t st) {
+  const long long n = (long long)planes * H * W;
+  const int grid = grid_for(n);
+  auto eptr = [&](int k) -> float* { return keep_all ? E + (long long)(k - 1) * n : E + (long long)((k - 1) % 3) * n; };
+  auto sptr = [&](int k) -> float* { return keep_all ? SK + (long long)k * n : SK; };
+  hipLaunchKernelGGL((morph_kernel<true, false>), dim3(grid), dim3(256), 0, st, planes, H, W, x, eptr(1));
+  for (int k = 0; k < SKEL_LEVELS; ++k) {
+    const float* ek = (k == 0) ? x : eptr(k);
+    float* ek2 = (k + 1 < SKEL_LEVELS) ? eptr(k + 2) : nullptr;
+    const float* sp = (k == 0) ? nullptr : sptr(k - 1);
+    if (k == 0)
+      hipLaunchKernelGGL((skel_level_kernel<true>), dim3(grid), dim3(256), 0, st, planes, H, W, ek, eptr(k + 1), sp, sptr(k), ek2);
+    else
+      hipLaunchKernelGGL((skel_level_kernel<false>), dim3(grid), dim3(256), 0, st, planes, H, W, ek, eptr(k + 1), sp, sptr(k), ek2);
+  }
+  return uh_check_launch("soft_skel");
+}
+
+extern "C" size_t uh_soft_skel_workspace(int planes, int H, int W) {
+  return (size_t)planes * H * W * 3 * sizeof(float);
+}
+
+extern "C" int uh_soft_skel(int planes, int H, int W, const float* x, float* skel, float* workspace, uh_stream s) {
+  UH_REQUIRE(planes > 0 && H > 0 && W > 0 && x && skel && workspace, "soft_skel: bad arguments");
+  return skel_forward(planes, H, W, x, workspace, skel, 0, (hipStream_t)s);
+}
+
+// workspace layout (floats), n = planes*H*W:
+//   E_pred[11n] | SK_pred[11n] | skel_true[n] | scratch[4n] | partial[7*SUM_BLOCKS] | coef[32]
+#define SUM_BLOCKS 1024
+static size_t cldice_ws_floats(long long n) { return (size_t)(27 * n + 7 * SUM_BLOCKS + 32); }
+
+extern "C" size_t uh_cldice_workspace(int planes, int H, int W) {
+  return cldice_ws_floats((long long)planes * H * W) * sizeof(float);
+}
+
+extern "C" int uh_cldice_forward(int planes, int H, int W, const float* y_true, const float* y_pred, float alpha,
+                                 float smooth, float* workspace, float* loss_out, uh_stream s) {
+  UH_REQUIRE(planes > 0 && H > 0 && W > 0 && y_true && y_pred && workspace && loss_out, "cldice_forward: bad arguments");
+  hipStream_t st = (hipStream_t)s;
+  const long long n = (long long)planes * H * W;
+  float* E = workspace;
+  float* SK = E + 11 * n;
+  float* SKT = SK + 11 * n;
+  float* scratch = SKT + n;
+  float* partial = scratch + 4 * n;
+  float* coef = partial + 7 * SUM_BLOCKS;
+  int rc = skel_forward(planes, H, W, y_pred, E, SK, 1, st);
+  if (rc) return rc;
+  rc = skel_forward(planes, H, W, y_true, scratch, SKT, 0, st);
+  if (rc) return rc;
+  int blocks = grid_for(n);
+  if (blocks > SUM_BLOCKS) blocks = SUM_BLOCKS;
+  hipLaunchKernelGGL(cldice_sums_kernel, dim3(blocks), dim3(256), 0, st, n, y_true, y_pred, SK + 10 * n, SKT, partial);
+  hipLaunchKernelGGL(cldice_finalize_kernel, dim3(1), dim3(256), 0, st, partial, blocks, alpha, smooth, coef);
+  hipError_t e = hipMemcpyAsync(loss_out, coef, sizeof(float), hipMemcpyDeviceToDevice, st);
+  if (e != hipSuccess) {
+    uh_set_error("cldice_forward: copy of the loss failed: %s", hipGetErrorString(e));
+    return UH_ERR_HIP;
+  }
+  return uh_check_launch("cldice_forward");
+}
+
+extern "C" int uh_cldice_backward(int planes, int H, int W, const float* y_true, const float* y_pred,
+                                  float* workspace, const float* grad_out, float* grad_pred, uh_stream s) {
+  UH_REQUIRE(planes > 0 && H > 0 && W > 0 && y_true && y_pred && workspace && grad_out && grad_pred,
+             "cldice_backward: bad arguments");
+  hipStream_t st = (hipStream_t)s;
+  const long long n = (long long)planes * H * W;
+  float* E = workspace;
+  float* SK = E + 11 * n;
+  float* SKT = SK + 11 * n;
+  float* scratch = SKT + n;
+  float* coef = scratch + 4 * n + 7 * SUM_BLOCKS;
+  float* gs[2] = {scratch, scratch + n};
+  float* ge[2] = {scratch + 2 * n, scratch + 3 * n};
+  const dim3 grid(uh_cdiv(W, BT), uh_cdiv(H, BT), planes);
+  for (int k = SKEL_LEVELS - 1; k >= 0; --k) {
+    BwdArgs a;
+    a.ek = (k == 0) ? y_pred : E + (long long)(k - 1) * n;
+    a.ek1 = E + (long long)k * n;
+    a.skel_prev = (k == 0) ? nullptr : SK + (long long)(k - 1) * n;
+    a.top = (k == SKEL_LEVELS - 1);
+    a.level0 = (k == 0);
+    a.gs_in = a.top ? nullptr : gs[k & 1];
+    a.ge1_in = a.top ? nullptr : ge[k & 1];
+    a.gs_out = (k == 0) ? nullptr : gs[(k - 1) & 1];
+    a.ge_out = (k == 0) ? grad_pred : ge[(k - 1) & 1];
+    a.yt = y_true;
+    a.skt = SKT;
+    a.coef = coef;
+    a.gout = grad_out;
+    a.H = H;
+    a.W = W;
+    hipLaunchKernelGGL(skel_bwd_level_kernel, grid, dim3(256), 0, st, a);
+  }
+  return uh_check_launch("cldice_backward");
+}
+
+// plain soft_dice (cl_dice.py:73-94) from the same sums, for reporting
+extern "C" int uh_cldice_read_terms(const float* workspace, int planes, int H, int W, float* out16, uh_stream s) {
+  UH_REQUIRE(workspace && out16, "cldice_read_terms: bad arguments");
+  const long long n = (long long)planes * H * W;
+  const float* coef = workspace + 27 * n + 7 * SUM_BLOCKS;
+  hipError_t e = hipMemcpyAsync(out16, coef, 17 * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)s);
+  if (e != hipSuccess) {
+    uh_set_error("cldice_read_terms: %s", hipGetErrorString(e));
+    return UH_ERR_HIP;
+  }
+  return UH_OK;
+}
