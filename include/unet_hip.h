@@ -52,7 +52,8 @@ enum {
                              over interior rows -> stat_partial[mtile][2][N]   (train-mode BN input) */
   UH_EPI_AFFINE_RELU = 1, /* out = relu(acc*scale[n] + shift[n]) on interior rows, 0 on pads (eval-mode BN folded) */
   UH_EPI_MASKED = 2,      /* out = acc (+bias if given) on interior rows, 0 on pads (dgrad, plain convs) */
-  UH_EPI_CONVT = 3        /* N = 4*Cout, n = tap*Cout+co: out[(b,2y+tap/2,2x+tap%2)][co] = acc + bias[co];
+  UH_EPI_CONVT = 3        /* n = tap*Cout+co: out[(b,2y+tap/2,2x+tap%2)][co] = acc + bias[co]; Cout = min(N/4, o_cstride-o_coff)
+                             (weight rows beyond 4*Cout are zero padding and are skipped);
                              out has geometry (B,2H,2W); pad rows of out are written as zero */
 };
 int uh_conv_gemm(int B, int H, int W,
@@ -77,6 +78,10 @@ int uh_conv_wgrad(int B, int H, int W,
 int uh_wgrad_reduce(const float* partial, int S, int N, int T, int K,
                     long long on, long long ot, long long sn, long long st, long long sk,
                     float* grad, int accumulate, uh_stream s);
+/* same, with an explicit distance between split slabs (partials whose rows are zero-padded beyond N*T*K) */
+int uh_wgrad_reduce_strided(const float* partial, int S, long long split_stride, int N, int T, int K,
+                            long long on, long long ot, long long sn, long long st, long long sk,
+                            float* grad, int accumulate, uh_stream s);
 
 /* ---- first layer: Conv2d(Cin<=4 -> Cout, 3x3, pad 1) on NCHW fp32 input (unet.py:99) ------ */
 int uh_conv_first_fwd(int B, int H, int W, int Cin, int Cout,
@@ -145,10 +150,59 @@ int uh_colsum_finalize(const float* partial, int P, int C, int fold, float* out,
 /* ---- 1x1 segmentation head Conv2d(C -> OC) (unet.py:173; lunext.py:257), fp32 NCHW logits ------ */
 int uh_head_fwd(int B, int H, int W, int C, int OC, const void* a, int a_cstride, int a_coff,
                 const float* w, const float* bias, float* logits_nchw, uh_stream s);
-int uh_head_bwd_parts(int B, int H, int W);
+int uh_head_bwd_parts(int B, int H, int W, int C);
 int uh_head_bwd(int B, int H, int W, int C, int OC, const void* a, int a_cstride, int a_coff,
                 const float* w, const float* dlogits_nchw,
                 void* da, int da_cstride, int da_coff, float* partial /*[P][OC][C+1]*/, uh_stream s);
+
+/* ---- LUNeXt blocks (models/lunext.py), padded-linear NHWC bf16 with C a multiple of 8 ----------------
+ * The 3-channel full-resolution level is carried zero-padded to 8 channels. */
+int uh_dw_parts(long long Mp, int C);
+/* depthwise Conv2d(C,C,3,pad 1,groups=C) (lunext.py:14-15,24), w9[t][c] fp32.  RAW_STATS: out = fp16(v) and
+ * partial[blk][2][C] = (sum v, sum v^2); AFFINE_RELU: out = relu(v*scale + shift + x) (eval-mode block). */
+int uh_dwconv3x3_fwd(int B, int H, int W, int C, const void* x, int x_cstride, int x_coff,
+                     const float* w9, const float* bias, int mode, const float* scale, const float* shift,
+                     const uint8_t* rowmask, void* out, int o_cstride, int o_coff, float* partial, uh_stream s);
+/* a = relu(y*scale + shift + x)   (lunext.py:25-28) and its backward: d = da*(.. > 0);
+ * reduce -> partial[P][2][C] (P = uh_bn_bwd_parts); apply -> dy = scale*(d - c0 - xhat*c1), dr = d */
+int uh_bn_res_relu_apply(long long Mp, int C, const void* y, int y_cstride, int y_coff,
+                         const void* x, int x_cstride, int x_coff, const float* scale, const float* shift,
+                         const uint8_t* rowmask, void* a, int a_cstride, int a_coff, uh_stream s);
+int uh_bn_res_relu_bwd_reduce(long long Mp, int C, const void* da, int da_cstride, int da_coff,
+                              const void* y, int y_cstride, int y_coff, const void* x, int x_cstride, int x_coff,
+                              const float* mean, const float* invstd, const float* scale, const float* shift,
+                              float* partial, uh_stream s);
+int uh_bn_res_relu_bwd_apply(long long Mp, int C, const void* da, int da_cstride, int da_coff,
+                             const void* y, int y_cstride, int y_coff, const void* x, int x_cstride, int x_coff,
+                             const float* mean, const float* invstd, const float* scale, const float* shift,
+                             const float* coef, const uint8_t* rowmask,
+                             void* dy, int dy_cstride, int dy_coff, void* dr, int dr_cstride, int dr_coff, uh_stream s);
+/* dx = dwconv(dy, flipped w9) + dr;  partial[blk][9][C] = sum_m dy[m][c]*x[m+off(t)][c] (blk < uh_dw_parts) */
+int uh_dwconv3x3_dgrad(int B, int H, int W, int C, const void* dy, int dy_cstride, int dy_coff,
+                       const float* w9, const void* dr, int dr_cstride, int dr_coff,
+                       const uint8_t* rowmask, void* dx, int dx_cstride, int dx_coff, uh_stream s);
+int uh_dwconv3x3_wgrad(int B, int H, int W, int C, const void* dy, int dy_cstride, int dy_coff,
+                       const void* x, int x_cstride, int x_coff, float* partial, uh_stream s);
+/* AttentionGate pointwise parts (lunext.py:100-117); z = [W1 g+b1 | W2 g+b2 | W3 (g+x)+b3], 3C channels */
+int uh_gate_fwd(long long Mp, int C, const void* z, int z_cstride, int z_coff, const void* x, int x_cstride,
+                int x_coff, void* out, int o_cstride, int o_coff, uh_stream s);
+int uh_gate_bwd(long long Mp, int C, const void* dout, int d_cstride, int d_coff, const void* z, int z_cstride,
+                int z_coff, const void* x, int x_cstride, int x_coff, const uint8_t* rowmask,
+                void* dz, int dz_cstride, int dz_coff, void* dxd, int dx_cstride, int dx_coff, uh_stream s);
+/* out = a + b (+ c when c != null) */
+int uh_add(long long Mp, int C, const void* a, int a_cstride, int a_coff, const void* b, int b_cstride, int b_coff,
+           const void* c, int c_cstride, int c_coff, void* out, int o_cstride, int o_coff, uh_stream s);
+/* fully fused gate for the 8-channel top level; wts = W1[8][8]|W2[8][8]|W3[8][8]|b1[8]|b2[8]|b3[8] fp32,
+ * partial[blk][216] (blk < uh_gate8_parts) holds the weight gradients in the same layout */
+int uh_gate8_fwd(long long Mp, const void* g, int g_cstride, int g_coff, const void* x, int x_cstride, int x_coff,
+                 const float* wts, const uint8_t* rowmask, void* out, int o_cstride, int o_coff, uh_stream s);
+int uh_gate8_parts(long long Mp);
+int uh_gate8_bwd(long long Mp, const void* dout, int d_cstride, int d_coff, const void* g, int g_cstride, int g_coff,
+                 const void* x, int x_cstride, int x_coff, const float* wts,
+                 void* dg, int dg_cstride, int dg_coff, void* dx, int dx_cstride, int dx_coff,
+                 float* partial, uh_stream s);
+/* NCHW fp32 image (Cin <= 8) -> 8-channel padded-linear bf16 */
+int uh_nchw_to_c8(int B, int Cin, int H, int W, const float* x, void* out, int o_cstride, int o_coff, uh_stream s);
 
 /* ---- clDice soft-skeleton loss, fp32 planes [planes][H][W] (losses/cl_dice.py) ---------------------
  * soft_erode (cl_dice.py:12-17): 5-point-cross minimum, out-of-image neighbours ignored; clamp != 0 first

@@ -64,3 +64,38 @@ class EmuUNet(ref_cpu.RefUNet):
             x = q(torch.cat([skips[4 - k], u], dim=1), None)
             x = self._cbr(f"conv_up{k}_2", self._cbr(f"conv_up{k}_1", x))
         return self.final_conv(x)
+
+
+class EmuLUNeXt(ref_cpu.RefLUNeXt):
+    """RefLUNeXt with the HIP path's storage roundings: bf16 activations and GEMM weights (depthwise,
+    8-channel gate and head weights stay fp32), fp16 BatchNorm inputs, bf16 gradients."""
+
+    def _dwb(self, blk, x):
+        y = q(F.conv2d(x, blk.depthwise.weight, blk.depthwise.bias, padding=1, groups=x.shape[1]), torch.float16)
+        return q(F.relu(blk.bn(y) + x), torch.bfloat16)
+
+    def _gate(self, att, g, x):
+        small = g.shape[1] < 64
+        wq = (lambda w: w) if small else w_bf16
+        rq = (lambda t: t) if small else (lambda t: q(t, torch.bfloat16))
+        z1 = rq(F.conv2d(g, wq(att.sigmoid_conv.weight), att.sigmoid_conv.bias))
+        z2 = rq(F.conv2d(g, wq(att.tanh_conv.weight), att.tanh_conv.bias))
+        s = rq(g + x)
+        z3 = rq(F.conv2d(s, wq(att.combine_conv.weight), att.combine_conv.bias))
+        return q(torch.sigmoid(z3) * x + torch.sigmoid(z1) * torch.tanh(z2), torch.bfloat16)
+
+    def forward(self, x):
+        x = q(x, torch.bfloat16)
+        skips = []
+        for lvl in range(1, 5):
+            x = self._dwb(getattr(self, f"conv{lvl}_2"), self._dwb(getattr(self, f"conv{lvl}_1"), x))
+            skips.append(x)
+            d = getattr(self, f"downconv{lvl}")
+            x = q(F.conv2d(x, w_bf16(d.weight), d.bias, stride=2), torch.bfloat16)
+        x = self._dwb(self.conv5_2, self._dwb(self.conv5_1, x))
+        for k in range(1, 5):
+            up = getattr(self, f"upconv{k}")
+            u = q(F.conv_transpose2d(x, w_bf16(up.weight), up.bias, stride=2), torch.bfloat16)
+            x = self._gate(getattr(self, f"att{k}"), u, skips[4 - k])
+            x = self._dwb(getattr(self, f"conv_up{k}_2"), self._dwb(getattr(self, f"conv_up{k}_1"), x))
+        return self.final_conv(x)

@@ -376,7 +376,7 @@ def test_colsum_and_head():
         lr.backward(dl)
         dld = dl.to(DEV)
         da = new_act(B, H, W, C, DEV)
-        hp_parts = lib.uh_head_bwd_parts(B, H, W)
+        hp_parts = lib.uh_head_bwd_parts(B, H, W, C)
         hp = torch.empty(hp_parts, OC, C + 1, device=DEV)
         call("uh_head_bwd", B, H, W, C, OC, a.ptr, a.cstride, a.coff, wd.data_ptr(), dld.data_ptr(), da.ptr, da.cstride,
              da.coff, hp.data_ptr(), S())

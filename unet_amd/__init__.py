@@ -8,7 +8,8 @@ Everything executes in hand-written HIP kernels behind the C ABI of include/unet
 """
 from ._lib import lib, LIB_PATH, HipKernelError          # noqa: F401  (fails loudly if the .so is missing)
 from .unet import UNet                                   # noqa: F401
+from .lunext import LUNeXt                               # noqa: F401
 from .model_utils import create_unet, create_lunext, save_model   # noqa: F401
 from .cl_dice import soft_dice_cldice, soft_cldice, soft_dice, SoftSkeletonize   # noqa: F401
 
-__all__ = ["UNet", "soft_dice_cldice", "soft_cldice", "soft_dice", "SoftSkeletonize", "create_unet", "create_lunext", "save_model", "lib", "LIB_PATH", "HipKernelError"]
+__all__ = ["UNet", "LUNeXt", "soft_dice_cldice", "soft_cldice", "soft_dice", "SoftSkeletonize", "create_unet", "create_lunext", "save_model", "lib", "LIB_PATH", "HipKernelError"]

@@ -28,6 +28,7 @@ SIGNATURES = {
     "uh_conv_wgrad_workspace": (Z, [I, I, I, I, I, I]),
     "uh_conv_wgrad": (I, [I, I, I, P, I, I, I, P, I, I, I, I, P, P]),
     "uh_wgrad_reduce": (I, [P, I, I, I, I, L, L, L, L, L, P, I, P]),
+    "uh_wgrad_reduce_strided": (I, [P, I, L, I, I, I, L, L, L, L, L, P, I, P]),
     "uh_conv_first_fwd": (I, [I, I, I, I, I, P, P, P, I, P, P, P, I, I, P, P]),
     "uh_conv_first_parts": (I, [I, I, I]),
     "uh_conv_first_wgrad": (I, [I, I, I, I, I, P, P, I, I, P, P]),
@@ -47,8 +48,22 @@ SIGNATURES = {
     "uh_colsum": (I, [L, I, P, I, I, P, P]),
     "uh_colsum_finalize": (I, [P, I, I, I, P, I, P]),
     "uh_head_fwd": (I, [I, I, I, I, I, P, I, I, P, P, P, P]),
-    "uh_head_bwd_parts": (I, [I, I, I]),
+    "uh_head_bwd_parts": (I, [I, I, I, I]),
     "uh_head_bwd": (I, [I, I, I, I, I, P, I, I, P, P, P, I, I, P, P]),
+    "uh_dw_parts": (I, [L, I]),
+    "uh_dwconv3x3_fwd": (I, [I, I, I, I, P, I, I, P, P, I, P, P, P, P, I, I, P, P]),
+    "uh_bn_res_relu_apply": (I, [L, I, P, I, I, P, I, I, P, P, P, P, I, I, P]),
+    "uh_bn_res_relu_bwd_reduce": (I, [L, I, P, I, I, P, I, I, P, I, I, P, P, P, P, P, P]),
+    "uh_bn_res_relu_bwd_apply": (I, [L, I, P, I, I, P, I, I, P, I, I, P, P, P, P, P, P, P, I, I, P, I, I, P]),
+    "uh_dwconv3x3_dgrad": (I, [I, I, I, I, P, I, I, P, P, I, I, P, P, I, I, P]),
+    "uh_dwconv3x3_wgrad": (I, [I, I, I, I, P, I, I, P, I, I, P, P]),
+    "uh_gate_fwd": (I, [L, I, P, I, I, P, I, I, P, I, I, P]),
+    "uh_gate_bwd": (I, [L, I, P, I, I, P, I, I, P, I, I, P, P, I, I, P, I, I, P]),
+    "uh_add": (I, [L, I, P, I, I, P, I, I, P, I, I, P, I, I, P]),
+    "uh_gate8_fwd": (I, [L, P, I, I, P, I, I, P, P, P, I, I, P]),
+    "uh_gate8_parts": (I, [L]),
+    "uh_gate8_bwd": (I, [L, P, I, I, P, I, I, P, I, I, P, P, I, I, P, I, I, P, P]),
+    "uh_nchw_to_c8": (I, [I, I, I, I, P, P, I, I, P]),
     "uh_soft_erode": (I, [I, I, I, P, P, I, P]),
     "uh_soft_dilate": (I, [I, I, I, P, P, P]),
     "uh_soft_skel_workspace": (Z, [I, I, I]),

@@ -4,69 +4,7 @@
 // moves 16 bytes (8 channels) per access, lanes of a wave walk the channel axis so a wave
 // touches whole rows, and per-channel sums are kept in registers across a grid-stride loop,
 // combined through LDS once per workgroup and written as one partial row per workgroup.
-#include "common.h"
-
-static inline int ew_rows_per_iter(int C) { return 256 / (C / 8); }
-static inline int ew_blocks(long long Mp, int C) {
-  const int rpi = ew_rows_per_iter(C);
-  long long b = (Mp + rpi - 1) / rpi;
-  if (b > 2048) b = 2048;
-  return (int)b;
-}
-#define EW_CHECK(name, C)                                                                              \
-  UH_REQUIRE((C) > 0 && (C) % 8 == 0 && (C) / 8 <= 256, name ": C=%d must be a multiple of 8, at most 2048", (C))
-
-// block-level combine of per-thread sums: threads with the same channel chunk cc = tid % cpr
-// hold sums for channels cc*8..cc*8+7; result row layout [NSTAT][C].
-template <int NSTAT>
-__device__ __forceinline__ void block_combine_store(float (&acc)[NSTAT][8], int C, int cpr, int rpi, float* lds,
-                                                    float* out_row) {
-  const int tid = threadIdx.x;
-  const int rr = tid / cpr, cc = tid % cpr;
-  const bool active = rr < rpi;
-  // lds[rr][stat][C]
-  if (active) {
-#pragma unroll
-    for (int s = 0; s < NSTAT; ++s)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) lds[(rr * NSTAT + s) * C + cc * 8 + j] = acc[s][j];
-  }
-  __syncthreads();
-  for (int i = tid; i < NSTAT * C; i += 256) {
-    float v = 0.f;
-    for (int r = 0; r < rpi; ++r) v += lds[r * NSTAT * C + i];
-    out_row[i] = v;
-  }
-}
-
-// ---- partial-row reductions: partial[P][ncols] -> per-column double sums ------------------------
-// one workgroup of 1024 threads handles 8 channels; thread (c8 = t&7, slot = t>>3) walks rows.
-template <int NSTAT>
-__device__ __forceinline__ void reduce_partials(const float* __restrict__ partial, int P, int C, int c0,
-                                                double (&out)[NSTAT], double* lds /*[128][NSTAT][8]*/) {
-  const int t = threadIdx.x, c8 = t & 7, slot = t >> 3;
-  double s[NSTAT];
-#pragma unroll
-  for (int k = 0; k < NSTAT; ++k) s[k] = 0.0;
-  if (c0 + c8 < C) {
-    for (int p = slot; p < P; p += 128) {
-#pragma unroll
-      for (int k = 0; k < NSTAT; ++k) s[k] += (double)partial[((long long)p * NSTAT + k) * C + c0 + c8];
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < NSTAT; ++k) lds[(slot * NSTAT + k) * 8 + c8] = s[k];
-  __syncthreads();
-  for (int stride = 64; stride > 0; stride >>= 1) {
-    if (slot < stride) {
-#pragma unroll
-      for (int k = 0; k < NSTAT; ++k) lds[(slot * NSTAT + k) * 8 + c8] += lds[((slot + stride) * NSTAT + k) * 8 + c8];
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int k = 0; k < NSTAT; ++k) out[k] = lds[k * 8 + c8];
-}
+#include "ew.h"
 
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ partial, int P, int C,
                                                            double count, const float* gamma, const float* beta,
@@ -526,7 +464,7 @@ static inline int head_bwd_blocks(int B, int H, int W, int C) {
   if (b > 1024) b = 1024;
   return (int)b;
 }
-extern "C" int uh_head_bwd_parts(int B, int H, int W) { return head_bwd_blocks(B, H, W, 64); }
+extern "C" int uh_head_bwd_parts(int B, int H, int W, int C) { return head_c_ok(C) ? head_bwd_blocks(B, H, W, C) : 0; }
 
 __global__ __launch_bounds__(256) void head_bwd_kernel(int B, int H, int W, int C, int OC, const char* __restrict__ a,
                                                        int a_cs, int a_co, const float* __restrict__ w,
@@ -584,7 +522,7 @@ extern "C" int uh_head_bwd(int B, int H, int W, int C, int OC, const void* a, in
                            const float* w, const float* dlogits, void* da, int da_cstride, int da_coff, float* partial,
                            uh_stream s) {
   UH_REQUIRE(B > 0 && H > 0 && W > 0 && OC > 0 && a && w && dlogits && da && partial, "head_bwd: bad arguments");
-  UH_REQUIRE(C == 64, "head_bwd: C=%d (only C=64 is built)", C);
+  UH_REQUIRE(head_c_ok(C), "head_bwd: C=%d must be a power of two in [8,512]", C);
   const int rpi = 256 / (C / 8);
   hipLaunchKernelGGL(head_bwd_kernel, dim3(head_bwd_blocks(B, H, W, C)), dim3(256), (size_t)rpi * C * 4, (hipStream_t)s,
                      B, H, W, C, OC, (const char*)a, a_cstride, a_coff, w, dlogits, (char*)da, da_cstride, da_coff,

@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmArgs p) {
       const int y = (int)(r % Hp);
       const long long b = r / Hp;
       const int Y = 2 * y + (t >> 1), X = 2 * x + (t & 1);
-      if (Y < oHp && X < oWp) {
+      if (t < 4 && Y < oHp && X < oWp) {        // t >= 4: zero-padded weight rows (N > 4*Cout)
         const U4 v = *(const U4*)(smem + row * C::PITCH + cc * 16);
         const long long om = (b * oHp + Y) * oWp + X;
         *(U4*)(p.out + (om * p.o_cstride + p.o_coff + co) * 2) = v;
@@ -254,7 +254,7 @@ extern "C" int uh_conv_gemm(int B, int H, int W, const void* a, int a_cstride, i
              "conv_gemm: bad A view (cstride=%d coff=%d K=%d)", a_cstride, a_coff, K);
   UH_REQUIRE(o_cstride % 8 == 0 && o_coff % 8 == 0, "conv_gemm: bad out view");
   if (mode == UH_EPI_CONVT) {
-    UH_REQUIRE(N % 4 == 0 && (N / 4) % 8 == 0 && o_cstride >= o_coff + N / 4, "conv_gemm: bad transposed-conv view");
+    UH_REQUIRE(o_cstride - o_coff >= 8, "conv_gemm: bad transposed-conv view");
     UH_REQUIRE(T == 1, "conv_gemm: transposed conv is a T=1 GEMM");
   } else {
     UH_REQUIRE(o_cstride >= o_coff + N, "conv_gemm: out view too narrow");
@@ -283,7 +283,8 @@ extern "C" int uh_conv_gemm(int B, int H, int W, const void* a, int a_cstride, i
   p.mode = mode;
   p.H = H;
   p.W = W;
-  p.Cout = (mode == UH_EPI_CONVT) ? N / 4 : N;
+  // transposed conv: Cout = N/4, or the width of the output window when that is narrower (N zero-padded to 64)
+  p.Cout = (mode == UH_EPI_CONVT) ? ((N / 4 < o_cstride - o_coff) ? N / 4 : o_cstride - o_coff) : N;
   hipStream_t st = (hipStream_t)s;
   if (use_wide_m(N)) {
     using C = Cfg<256, 64>;

@@ -194,10 +194,10 @@ extern "C" int uh_conv_wgrad(int B, int H, int W, const void* dy, int dy_cstride
   return uh_check_launch("conv_wgrad");
 }
 
-// grad[n*sn + t*st + k*sk] (+)= sum_s partial[s*N*T*K + n*on + t*ot + k]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int S, int N, int T, int K, long long on,
-                                    long long ot, long long sn, long long st, long long sk, float* __restrict__ grad,
-                                    int accumulate) {
+// grad[n*sn + t*st + k*sk] (+)= sum_s partial[s*split_stride + n*on + t*ot + k]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int S, long long split_stride, int N, int T,
+                                    int K, long long on, long long ot, long long sn, long long st, long long sk,
+                                    float* __restrict__ grad, int accumulate) {
   const long long total = (long long)N * T * K;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int k = (int)(i % K);
@@ -206,19 +206,25 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int S, in
     const int n = (int)(r / T);
     const long long src = n * on + t * ot + k;
     float v = 0.f;
-    for (int s = 0; s < S; ++s) v += partial[s * total + src];
+    for (int s = 0; s < S; ++s) v += partial[s * split_stride + src];
     const long long dst = n * sn + t * st + k * sk;
     grad[dst] = accumulate ? grad[dst] + v : v;
   }
 }
 
-extern "C" int uh_wgrad_reduce(const float* partial, int S, int N, int T, int K, long long on, long long ot,
-                               long long sn, long long st, long long sk, float* grad, int accumulate, uh_stream s) {
-  UH_REQUIRE(partial && grad && S > 0 && N > 0 && T > 0 && K > 0, "wgrad_reduce: bad arguments");
+extern "C" int uh_wgrad_reduce_strided(const float* partial, int S, long long split_stride, int N, int T, int K,
+                                       long long on, long long ot, long long sn, long long st, long long sk,
+                                       float* grad, int accumulate, uh_stream s) {
+  UH_REQUIRE(partial && grad && S > 0 && N > 0 && T > 0 && K > 0 && split_stride > 0, "wgrad_reduce: bad arguments");
   const long long total = (long long)N * T * K;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, partial, S, N, T, K, on, ot, sn,
-                     st, sk, grad, accumulate);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, partial, S, split_stride, N, T, K,
+                     on, ot, sn, st, sk, grad, accumulate);
   return uh_check_launch("wgrad_reduce");
+}
+
+extern "C" int uh_wgrad_reduce(const float* partial, int S, int N, int T, int K, long long on, long long ot,
+                               long long sn, long long st, long long sk, float* grad, int accumulate, uh_stream s) {
+  return uh_wgrad_reduce_strided(partial, S, (long long)N * T * K, N, T, K, on, ot, sn, st, sk, grad, accumulate, s);
 }

@@ -1,0 +1,606 @@
+// LUNeXt blocks (models/lunext.py of the reference) on gfx950: all bandwidth bound.
+//   DepthwiseConvBlock  relu(BN(dwconv3x3(x)) + x)                            lunext.py:6-30
+//   AttentionGate       sigmoid(W3(g+x))*x + sigmoid(W1 g)*tanh(W2 g)         lunext.py:76-122
+// Tensors are padded-linear NHWC bf16 (common.h) with C a multiple of 8; the 3-channel full-resolution
+// level is carried with its channels zero-padded to 8, so one 16-byte lane access is one pixel.
+// The 1x1 convolutions of the gate at C >= 64 run on the MFMA GEMM (conv_gemm.hip); here are the depthwise
+// stencil (forward, input gradient, weight gradient), BatchNorm+residual+ReLU and its backward, the gate's
+// pointwise parts, and the fully fused 8-channel gate of the top level.
+#include "ew.h"
+
+// ---- depthwise 3x3, pad 1 ------------------------------------------------------------------------------------
+// v = sum_t x[m+off(t)][c]*w9[t][c] + bias[c];  train (RAW_STATS): out = fp16(v) + per-workgroup (sum v, sum v^2);
+// eval (AFFINE_RELU): out = bf16(relu(v*scale + shift + x[m][c])).
+__global__ __launch_bounds__(256) void dwconv_fwd_kernel(long long Mp, int C, int Wp, const char* __restrict__ x,
+                                                         int x_cs, int x_co, const float* __restrict__ w9,
+                                                         const float* __restrict__ bias, int mode,
+                                                         const float* __restrict__ scale,
+                                                         const float* __restrict__ shift,
+                                                         const uint8_t* __restrict__ rowmask, char* __restrict__ out,
+                                                         int o_cs, int o_co, float* __restrict__ partial) {
+  extern __shared__ float lds[];
+  const int cpr = C / 8, rpi = 256 / cpr;
+  const int rr = threadIdx.x / cpr, cc = threadIdx.x % cpr;
+  float acc[2][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[0][j] = acc[1][j] = 0.f;
+  if (rr < rpi) {
+    float w[9][8], b[8], sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      b[j] = bias ? bias[cc * 8 + j] : 0.f;
+      sc[j] = mode == UH_EPI_AFFINE_RELU ? scale[cc * 8 + j] : 0.f;
+      sh[j] = mode == UH_EPI_AFFINE_RELU ? shift[cc * 8 + j] : 0.f;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) w[t][j] = w9[t * C + cc * 8 + j];
+    }
+    for (long long m = (long long)blockIdx.x * rpi + rr; m < Mp; m += (long long)gridDim.x * rpi) {
+      U4 o = {0u, 0u, 0u, 0u};
+      if (rowmask[m]) {
+        float v[8], xc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = b[j];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const long long mm = m + (t / 3 - 1) * Wp + (t % 3 - 1);
+          float f[8];
+          unpack8(*(const U4*)(x + (mm * x_cs + x_co + cc * 8) * 2), f);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += f[j] * w[t][j];
+          if (t == 4) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xc[j] = f[j];
+          }
+        }
+        if (mode == UH_EPI_AFFINE_RELU) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j] * sc[j] + sh[j] + xc[j], 0.f);
+          o = pack8(v);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            acc[0][j] += v[j];
+            acc[1][j] += v[j] * v[j];
+          }
+          o = pack8h(v);
+        }
+      }
+      *(U4*)(out + (m * o_cs + o_co + cc * 8) * 2) = o;
+    }
+  }
+  if (mode == UH_EPI_RAW_STATS) block_combine_store<2>(acc, C, cpr, rpi, lds, partial + (long long)blockIdx.x * 2 * C);
+}
+
+extern "C" int uh_dw_parts(long long Mp, int C) { return (C > 0 && C % 8 == 0 && C / 8 <= 256) ? ew_blocks(Mp, C) : 0; }
+
+extern "C" int uh_dwconv3x3_fwd(int B, int H, int W, int C, const void* x, int x_cstride, int x_coff,
+                                const float* w9, const float* bias, int mode, const float* scale, const float* shift,
+                                const uint8_t* rowmask, void* out, int o_cstride, int o_coff, float* partial,
+                                uh_stream s) {
+  EW_CHECK("dwconv3x3_fwd", C);
+  UH_REQUIRE(B > 0 && H > 0 && W > 0 && x && w9 && rowmask && out, "dwconv3x3_fwd: bad arguments");
+  UH_REQUIRE(mode == UH_EPI_RAW_STATS || mode == UH_EPI_AFFINE_RELU, "dwconv3x3_fwd: bad mode %d", mode);
+  UH_REQUIRE(mode != UH_EPI_RAW_STATS || partial, "dwconv3x3_fwd: RAW_STATS needs partial");
+  UH_REQUIRE(mode != UH_EPI_AFFINE_RELU || (scale && shift), "dwconv3x3_fwd: AFFINE_RELU needs scale/shift");
+  const long long Mp = uh_mp(B, H, W);
+  const int rpi = ew_rows_per_iter(C);
+  hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(ew_blocks(Mp, C)), dim3(256), (size_t)rpi * 2 * C * 4, (hipStream_t)s, Mp,
+                     C, W + 1, (const char*)x, x_cstride, x_coff, w9, bias, mode, scale, shift, rowmask, (char*)out,
+                     o_cstride, o_coff, partial);
+  return uh_check_launch("dwconv3x3_fwd");
+}
+
+// ---- BatchNorm + residual + ReLU: a = relu(y*scale + shift + x) ---------------------------------------------------
+__global__ __launch_bounds__(256) void bn_res_relu_apply_kernel(long long Mp, int C, const char* __restrict__ y,
+                                                                int y_cs, int y_co, const char* __restrict__ x,
+                                                                int x_cs, int x_co, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift,
+                                                                const uint8_t* __restrict__ rowmask,
+                                                                char* __restrict__ a, int a_cs, int a_co) {
+  const int cpr = C / 8, rpi = 256 / cpr;
+  const int rr = threadIdx.x / cpr, cc = threadIdx.x % cpr;
+  if (rr >= rpi) return;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    sc[j] = scale[cc * 8 + j];
+    sh[j] = shift[cc * 8 + j];
+  }
+  for (long long m = (long long)blockIdx.x * rpi + rr; m < Mp; m += (long long)gridDim.x * rpi) {
+    U4 o = {0u, 0u, 0u, 0u};
+    if (rowmask[m]) {
+      float f[8], r[8];
+      unpack8h(*(const U4*)(y + (m * y_cs + y_co + cc * 8) * 2), f);
+      unpack8(*(const U4*)(x + (m * x_cs + x_co + cc * 8) * 2), r);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j] * sc[j] + sh[j] + r[j], 0.f);
+      o = pack8(f);
+    }
+    *(U4*)(a + (m * a_cs + a_co + cc * 8) * 2) = o;
+  }
+}
+
+extern "C" int uh_bn_res_relu_apply(long long Mp, int C, const void* y, int y_cstride, int y_coff, const void* x,
+                                    int x_cstride, int x_coff, const float* scale, const float* shift,
+                                    const uint8_t* rowmask, void* a, int a_cstride, int a_coff, uh_stream s) {
+  EW_CHECK("bn_res_relu_apply", C);
+  UH_REQUIRE(Mp > 0 && y && x && scale && shift && rowmask && a, "bn_res_relu_apply: bad arguments");
+  hipLaunchKernelGGL(bn_res_relu_apply_kernel, dim3(ew_blocks(Mp, C)), dim3(256), 0, (hipStream_t)s, Mp, C,
+                     (const char*)y, y_cstride, y_coff, (const char*)x, x_cstride, x_coff, scale, shift, rowmask,
+                     (char*)a, a_cstride, a_coff);
+  return uh_check_launch("bn_res_relu_apply");
+}
+
+// backward: d = da * (y*scale + shift + x > 0); partial = (sum d, sum d*xhat)
+__global__ __launch_bounds__(256) void bn_res_relu_bwd_reduce_kernel(
+    long long Mp, int C, const char* __restrict__ da, int da_cs, int da_co, const char* __restrict__ y, int y_cs,
+    int y_co, const char* __restrict__ x, int x_cs, int x_co, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ scale, const float* __restrict__ shift,
+    float* __restrict__ partial) {
+  extern __shared__ float lds[];
+  const int cpr = C / 8, rpi = 256 / cpr;
+  const int rr = threadIdx.x / cpr, cc = threadIdx.x % cpr;
+  float acc[2][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[0][j] = acc[1][j] = 0.f;
+  if (rr < rpi) {
+    float sc[8], sh[8], mu[8], is[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      sc[j] = scale[cc * 8 + j];
+      sh[j] = shift[cc * 8 + j];
+      mu[j] = mean[cc * 8 + j];
+      is[j] = invstd[cc * 8 + j];
+    }
+    for (long long m = (long long)blockIdx.x * rpi + rr; m < Mp; m += (long long)gridDim.x * rpi) {
+      float g[8], v[8], r[8];
+      unpack8(*(const U4*)(da + (m * da_cs + da_co + cc * 8) * 2), g);
+      unpack8h(*(const U4*)(y + (m * y_cs + y_co + cc * 8) * 2), v);
+      unpack8(*(const U4*)(x + (m * x_cs + x_co + cc * 8) * 2), r);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float d = (v[j] * sc[j] + sh[j] + r[j] > 0.f) ? g[j] : 0.f;
+        acc[0][j] += d;
+        acc[1][j] += d * (v[j] - mu[j]) * is[j];
+      }
+    }
+  }
+  block_combine_store<2>(acc, C, cpr, rpi, lds, partial + (long long)blockIdx.x * 2 * C);
+}
+
+extern "C" int uh_bn_res_relu_bwd_reduce(long long Mp, int C, const void* da, int da_cstride, int da_coff,
+                                         const void* y, int y_cstride, int y_coff, const void* x, int x_cstride,
+                                         int x_coff, const float* mean, const float* invstd, const float* scale,
+                                         const float* shift, float* partial, uh_stream s) {
+  EW_CHECK("bn_res_relu_bwd_reduce", C);
+  UH_REQUIRE(Mp > 0 && da && y && x && mean && invstd && scale && shift && partial, "bn_res_relu_bwd_reduce: bad arguments");
+  const int rpi = ew_rows_per_iter(C);
+  hipLaunchKernelGGL(bn_res_relu_bwd_reduce_kernel, dim3(ew_blocks(Mp, C)), dim3(256), (size_t)rpi * 2 * C * 4,
+                     (hipStream_t)s, Mp, C, (const char*)da, da_cstride, da_coff, (const char*)y, y_cstride, y_coff,
+                     (const char*)x, x_cstride, x_coff, mean, invstd, scale, shift, partial);
+  return uh_check_launch("bn_res_relu_bwd_reduce");
+}
+
+// dy = scale*(d - coef0 - xhat*coef1)  (gradient of the depthwise conv output),  dr = d  (residual branch)
+__global__ __launch_bounds__(256) void bn_res_relu_bwd_apply_kernel(
+    long long Mp, int C, const char* __restrict__ da, int da_cs, int da_co, const char* __restrict__ y, int y_cs,
+    int y_co, const char* __restrict__ x, int x_cs, int x_co, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ coef, const uint8_t* __restrict__ rowmask, char* __restrict__ dy, int dy_cs, int dy_co,
+    char* __restrict__ dr, int dr_cs, int dr_co) {
+  const int cpr = C / 8, rpi = 256 / cpr;
+  const int rr = threadIdx.x / cpr, cc = threadIdx.x % cpr;
+  if (rr >= rpi) return;
+  float sc[8], sh[8], mu[8], is[8], c0[8], c1[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = cc * 8 + j;
+    sc[j] = scale[c];
+    sh[j] = shift[c];
+    mu[j] = mean[c];
+    is[j] = invstd[c];
+    c0[j] = coef[c];
+    c1[j] = coef[C + c];
+  }
+  for (long long m = (long long)blockIdx.x * rpi + rr; m < Mp; m += (long long)gridDim.x * rpi) {
+    U4 o = {0u, 0u, 0u, 0u}, o2 = {0u, 0u, 0u, 0u};
+    if (rowmask[m]) {
+      float g[8], v[8], r[8];
+      unpack8(*(const U4*)(da + (m * da_cs + da_co + cc * 8) * 2), g);
+      unpack8h(*(const U4*)(y + (m * y_cs + y_co + cc * 8) * 2), v);
+      unpack8(*(const U4*)(x + (m * x_cs + x_co + cc * 8) * 2), r);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float d = (v[j] * sc[j] + sh[j] + r[j] > 0.f) ? g[j] : 0.f;
+        const float xh = (v[j] - mu[j]) * is[j];
+        r[j] = d;
+        g[j] = sc[j] * (d - c0[j] - xh * c1[j]);
+      }
+      o = pack8(g);
+      o2 = pack8(r);
+    }
+    *(U4*)(dy + (m * dy_cs + dy_co + cc * 8) * 2) = o;
+    *(U4*)(dr + (m * dr_cs + dr_co + cc * 8) * 2) = o2;
+  }
+}
+
+extern "C" int uh_bn_res_relu_bwd_apply(long long Mp, int C, const void* da, int da_cstride, int da_coff,
+                                        const void* y, int y_cstride, int y_coff, const void* x, int x_cstride,
+                                        int x_coff, const float* mean, const float* invstd, const float* scale,
+                                        const float* shift, const float* coef, const uint8_t* rowmask, void* dy,
+                                        int dy_cstride, int dy_coff, void* dr, int dr_cstride, int dr_coff,
+                                        uh_stream s) {
+  EW_CHECK("bn_res_relu_bwd_apply", C);
+  UH_REQUIRE(Mp > 0 && da && y && x && mean && invstd && scale && shift && coef && rowmask && dy && dr,
+             "bn_res_relu_bwd_apply: bad arguments");
+  hipLaunchKernelGGL(bn_res_relu_bwd_apply_kernel, dim3(ew_blocks(Mp, C)), dim3(256), 0, (hipStream_t)s, Mp, C,
+                     (const char*)da, da_cstride, da_coff, (const char*)y, y_cstride, y_coff, (const char*)x, x_cstride,
+                     x_coff, mean, invstd, scale, shift, coef, rowmask, (char*)dy, dy_cstride, dy_coff, (char*)dr,
+                     dr_cstride, dr_coff);
+  return uh_check_launch("bn_res_relu_bwd_apply");
+}
+
+// dx[m][c] = sum_t dy[m - off(t)][c]*w9[t][c] + dr[m][c]
+__global__ __launch_bounds__(256) void dwconv_dgrad_kernel(long long Mp, int C, int Wp, const char* __restrict__ dy,
+                                                           int dy_cs, int dy_co, const float* __restrict__ w9,
+                                                           const char* __restrict__ dr, int dr_cs, int dr_co,
+                                                           const uint8_t* __restrict__ rowmask,
+                                                           char* __restrict__ dx, int dx_cs, int dx_co) {
+  const int cpr = C / 8, rpi = 256 / cpr;
+  const int rr = threadIdx.x / cpr, cc = threadIdx.x % cpr;
+  if (rr >= rpi) return;
+  float w[9][8];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[t][j] = w9[t * C + cc * 8 + j];
+  for (long long m = (long long)blockIdx.x * rpi + rr; m < Mp; m += (long long)gridDim.x * rpi) {
+    U4 o = {0u, 0u, 0u, 0u};
+    if (rowmask[m]) {
+      float v[8];
+      if (dr) {
+        unpack8(*(const U4*)(dr + (m * dr_cs + dr_co + cc * 8) * 2), v);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+      }
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const long long mm = m - ((t / 3 - 1) * Wp + (t % 3 - 1));
+        float f[8];
+        unpack8(*(const U4*)(dy + (mm * dy_cs + dy_co + cc * 8) * 2), f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += f[j] * w[t][j];
+      }
+      o = pack8(v);
+    }
+    *(U4*)(dx + (m * dx_cs + dx_co + cc * 8) * 2) = o;
+  }
+}
+
+extern "C" int uh_dwconv3x3_dgrad(int B, int H, int W, int C, const void* dy, int dy_cstride, int dy_coff,
+                                  const float* w9, const void* dr, int dr_cstride, int dr_coff,
+                                  const uint8_t* rowmask, void* dx, int dx_cstride, int dx_coff, uh_stream s) {
+  EW_CHECK("dwconv3x3_dgrad", C);
+  UH_REQUIRE(B > 0 && H > 0 && W > 0 && dy && w9 && rowmask && dx, "dwconv3x3_dgrad: bad arguments");
+  const long long Mp = uh_mp(B, H, W);
+  hipLaunchKernelGGL(dwconv_dgrad_kernel, dim3(ew_blocks(Mp, C)), dim3(256), 0, (hipStream_t)s, Mp, C, W + 1,
+                     (const char*)dy, dy_cstride, dy_coff, w9, (const char*)dr, dr_cstride, dr_coff, rowmask,
+                     (char*)dx, dx_cstride, dx_coff);
+  return uh_check_launch("dwconv3x3_dgrad");
+}
+
+// partial[blk][9][C]: sum_m dy[m][c] * x[m + off(t)][c]
+__global__ __launch_bounds__(256) void dwconv_wgrad_kernel(long long Mp, int C, int Wp, const char* __restrict__ dy,
+                                                           int dy_cs, int dy_co, const char* __restrict__ x, int x_cs,
+                                                           int x_co, float* __restrict__ partial) {
+  extern __shared__ float lds[];
+  const int cpr = C / 8, rpi = 256 / cpr;
+  const int rr = threadIdx.x / cpr, cc = threadIdx.x % cpr;
+  float acc[9][8];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
+  if (rr < rpi) {
+    for (long long m = (long long)blockIdx.x * rpi + rr; m < Mp; m += (long long)gridDim.x * rpi) {
+      float g[8];
+      unpack8(*(const U4*)(dy + (m * dy_cs + dy_co + cc * 8) * 2), g);   // zero on pad rows
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const long long mm = m + (t / 3 - 1) * Wp + (t % 3 - 1);
+        float f[8];
+        unpack8(*(const U4*)(x + (mm * x_cs + x_co + cc * 8) * 2), f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[t][j] += g[j] * f[j];
+      }
+    }
+  }
+  float* row = partial + (long long)blockIdx.x * 9 * C;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    float one[1][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) one[0][j] = acc[t][j];
+    __syncthreads();
+    block_combine_store<1>(one, C, cpr, rpi, lds, row + t * C);
+  }
+}
+
+extern "C" int uh_dwconv3x3_wgrad(int B, int H, int W, int C, const void* dy, int dy_cstride, int dy_coff,
+                                  const void* x, int x_cstride, int x_coff, float* partial, uh_stream s) {
+  EW_CHECK("dwconv3x3_wgrad", C);
+  UH_REQUIRE(B > 0 && H > 0 && W > 0 && dy && x && partial, "dwconv3x3_wgrad: bad arguments");
+  const long long Mp = uh_mp(B, H, W);
+  const int rpi = ew_rows_per_iter(C);
+  hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3(ew_blocks(Mp, C)), dim3(256), (size_t)rpi * C * 4, (hipStream_t)s, Mp, C,
+                     W + 1, (const char*)dy, dy_cstride, dy_coff, (const char*)x, x_cstride, x_coff, partial);
+  return uh_check_launch("dwconv3x3_wgrad");
+}
+
+// ---- attention gate, pointwise parts (C >= 64; z = [z1 | z2 | z3] pre-activations, 3C channels) ----------------------
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf(-v)); }
+
+__global__ __launch_bounds__(256) void gate_fwd_kernel(long long Mp, int C, const char* __restrict__ z, int z_cs,
+                                                       int z_co, const char* __restrict__ x, int x_cs, int x_co,
+                                                       char* __restrict__ out, int o_cs, int o_co) {
+  const int cpr = C / 8, rpi = 256 / cpr;
+  const int rr = threadIdx.x / cpr, cc = threadIdx.x % cpr;
+  if (rr >= rpi) return;
+  for (long long m = (long long)blockIdx.x * rpi + rr; m < Mp; m += (long long)gridDim.x * rpi) {
+    float z1[8], z2[8], z3[8], xv[8];
+    const char* zr = z + (m * z_cs + z_co + cc * 8) * 2;
+    unpack8(*(const U4*)zr, z1);
+    unpack8(*(const U4*)(zr + C * 2), z2);
+    unpack8(*(const U4*)(zr + C * 4), z3);
+    unpack8(*(const U4*)(x + (m * x_cs + x_co + cc * 8) * 2), xv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xv[j] = sigmoidf_(z3[j]) * xv[j] + sigmoidf_(z1[j]) * tanhf(z2[j]);
+    // pad rows: z holds zeros there (masked GEMM epilogue) and x is zero, so the result is 0.5*tanh(0) = 0
+    *(U4*)(out + (m * o_cs + o_co + cc * 8) * 2) = pack8(xv);
+  }
+}
+
+extern "C" int uh_gate_fwd(long long Mp, int C, const void* z, int z_cstride, int z_coff, const void* x, int x_cstride,
+                           int x_coff, void* out, int o_cstride, int o_coff, uh_stream s) {
+  EW_CHECK("gate_fwd", C);
+  UH_REQUIRE(Mp > 0 && z && x && out && z_cstride >= z_coff + 3 * C, "gate_fwd: bad arguments");
+  hipLaunchKernelGGL(gate_fwd_kernel, dim3(ew_blocks(Mp, C)), dim3(256), 0, (hipStream_t)s, Mp, C, (const char*)z,
+                     z_cstride, z_coff, (const char*)x, x_cstride, x_coff, (char*)out, o_cstride, o_coff);
+  return uh_check_launch("gate_fwd");
+}
+
+// dz1 = dout*c*b*(1-b), dz2 = dout*b*(1-c^2), dz3 = dout*x*a*(1-a), dxd = dout*a
+__global__ __launch_bounds__(256) void gate_bwd_kernel(long long Mp, int C, const char* __restrict__ dout, int d_cs,
+                                                       int d_co, const char* __restrict__ z, int z_cs, int z_co,
+                                                       const char* __restrict__ x, int x_cs, int x_co,
+                                                       const uint8_t* __restrict__ rowmask, char* __restrict__ dz,
+                                                       int dz_cs, int dz_co, char* __restrict__ dxd, int dx_cs,
+                                                       int dx_co) {
+  const int cpr = C / 8, rpi = 256 / cpr;
+  const int rr = threadIdx.x / cpr, cc = threadIdx.x % cpr;
+  if (rr >= rpi) return;
+  for (long long m = (long long)blockIdx.x * rpi + rr; m < Mp; m += (long long)gridDim.x * rpi) {
+    float z1[8], z2[8], z3[8], xv[8], g[8], o1[8], o2[8], o3[8], ox[8];
+    const bool on = rowmask[m];
+    const char* zr = z + (m * z_cs + z_co + cc * 8) * 2;
+    unpack8(*(const U4*)zr, z1);
+    unpack8(*(const U4*)(zr + C * 2), z2);
+    unpack8(*(const U4*)(zr + C * 4), z3);
+    unpack8(*(const U4*)(x + (m * x_cs + x_co + cc * 8) * 2), xv);
+    unpack8(*(const U4*)(dout + (m * d_cs + d_co + cc * 8) * 2), g);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float b = sigmoidf_(z1[j]), c = tanhf(z2[j]), a = sigmoidf_(z3[j]);
+      const float d = on ? g[j] : 0.f;
+      o1[j] = d * c * b * (1.f - b);
+      o2[j] = d * b * (1.f - c * c);
+      o3[j] = d * xv[j] * a * (1.f - a);
+      ox[j] = d * a;
+    }
+    char* dr = dz + (m * dz_cs + dz_co + cc * 8) * 2;
+    *(U4*)dr = pack8(o1);
+    *(U4*)(dr + C * 2) = pack8(o2);
+    *(U4*)(dr + C * 4) = pack8(o3);
+    *(U4*)(dxd + (m * dx_cs + dx_co + cc * 8) * 2) = pack8(ox);
+  }
+}
+
+extern "C" int uh_gate_bwd(long long Mp, int C, const void* dout, int d_cstride, int d_coff, const void* z,
+                           int z_cstride, int z_coff, const void* x, int x_cstride, int x_coff,
+                           const uint8_t* rowmask, void* dz, int dz_cstride, int dz_coff, void* dxd, int dx_cstride,
+                           int dx_coff, uh_stream s) {
+  EW_CHECK("gate_bwd", C);
+  UH_REQUIRE(Mp > 0 && dout && z && x && rowmask && dz && dxd, "gate_bwd: bad arguments");
+  hipLaunchKernelGGL(gate_bwd_kernel, dim3(ew_blocks(Mp, C)), dim3(256), 0, (hipStream_t)s, Mp, C, (const char*)dout,
+                     d_cstride, d_coff, (const char*)z, z_cstride, z_coff, (const char*)x, x_cstride, x_coff, rowmask,
+                     (char*)dz, dz_cstride, dz_coff, (char*)dxd, dx_cstride, dx_coff);
+  return uh_check_launch("gate_bwd");
+}
+
+// out = a + b (+ c)
+__global__ __launch_bounds__(256) void add_kernel(long long Mp, int C, const char* __restrict__ a, int a_cs, int a_co,
+                                                  const char* __restrict__ b, int b_cs, int b_co,
+                                                  const char* __restrict__ c, int c_cs, int c_co,
+                                                  char* __restrict__ out, int o_cs, int o_co) {
+  const int cpr = C / 8, rpi = 256 / cpr;
+  const int rr = threadIdx.x / cpr, cc = threadIdx.x % cpr;
+  if (rr >= rpi) return;
+  for (long long m = (long long)blockIdx.x * rpi + rr; m < Mp; m += (long long)gridDim.x * rpi) {
+    float u[8], v[8];
+    unpack8(*(const U4*)(a + (m * a_cs + a_co + cc * 8) * 2), u);
+    unpack8(*(const U4*)(b + (m * b_cs + b_co + cc * 8) * 2), v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) u[j] += v[j];
+    if (c) {
+      unpack8(*(const U4*)(c + (m * c_cs + c_co + cc * 8) * 2), v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) u[j] += v[j];
+    }
+    *(U4*)(out + (m * o_cs + o_co + cc * 8) * 2) = pack8(u);
+  }
+}
+
+extern "C" int uh_add(long long Mp, int C, const void* a, int a_cstride, int a_coff, const void* b, int b_cstride,
+                      int b_coff, const void* c, int c_cstride, int c_coff, void* out, int o_cstride, int o_coff,
+                      uh_stream s) {
+  EW_CHECK("add", C);
+  UH_REQUIRE(Mp > 0 && a && b && out, "add: bad arguments");
+  hipLaunchKernelGGL(add_kernel, dim3(ew_blocks(Mp, C)), dim3(256), 0, (hipStream_t)s, Mp, C, (const char*)a, a_cstride,
+                     a_coff, (const char*)b, b_cstride, b_coff, (const char*)c, c_cstride, c_coff, (char*)out,
+                     o_cstride, o_coff);
+  return uh_check_launch("add");
+}
+
+// ---- the 8-channel gate of the top level, fully fused -------------------------------------------------------------------
+// wts: W1[8][8] | W2[8][8] | W3[8][8] | b1[8] | b2[8] | b3[8]   (fp32, [co][ci], zero padded beyond the real channels)
+#define G8_W 216
+__global__ __launch_bounds__(256) void gate8_fwd_kernel(long long Mp, const char* __restrict__ g, int g_cs, int g_co,
+                                                        const char* __restrict__ x, int x_cs, int x_co,
+                                                        const float* __restrict__ wts,
+                                                        const uint8_t* __restrict__ rowmask, char* __restrict__ out,
+                                                        int o_cs, int o_co) {
+  __shared__ float w[G8_W];
+  for (int i = threadIdx.x; i < G8_W; i += 256) w[i] = wts[i];
+  __syncthreads();
+  for (long long m = (long long)blockIdx.x * 256 + threadIdx.x; m < Mp; m += (long long)gridDim.x * 256) {
+    float gv[8], xv[8], o[8];
+    if (!rowmask[m]) {   // the biases make the gate non-zero at zero input: pad rows must be written as zero
+      *(U4*)(out + (m * o_cs + o_co) * 2) = U4{0u, 0u, 0u, 0u};
+      continue;
+    }
+    unpack8(*(const U4*)(g + (m * g_cs + g_co) * 2), gv);
+    unpack8(*(const U4*)(x + (m * x_cs + x_co) * 2), xv);
+#pragma unroll
+    for (int co = 0; co < 8; ++co) {
+      float z1 = w[192 + co], z2 = w[200 + co], z3 = w[208 + co];
+#pragma unroll
+      for (int ci = 0; ci < 8; ++ci) {
+        z1 += w[co * 8 + ci] * gv[ci];
+        z2 += w[64 + co * 8 + ci] * gv[ci];
+        z3 += w[128 + co * 8 + ci] * (gv[ci] + xv[ci]);
+      }
+      o[co] = sigmoidf_(z3) * xv[co] + sigmoidf_(z1) * tanhf(z2);
+    }
+    *(U4*)(out + (m * o_cs + o_co) * 2) = pack8(o);
+  }
+}
+
+extern "C" int uh_gate8_fwd(long long Mp, const void* g, int g_cstride, int g_coff, const void* x, int x_cstride,
+                            int x_coff, const float* wts, const uint8_t* rowmask, void* out, int o_cstride,
+                            int o_coff, uh_stream s) {
+  UH_REQUIRE(Mp > 0 && g && x && wts && rowmask && out, "gate8_fwd: bad arguments");
+  long long blocks = (Mp + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(gate8_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, Mp, (const char*)g,
+                     g_cstride, g_coff, (const char*)x, x_cstride, x_coff, wts, rowmask, (char*)out, o_cstride, o_coff);
+  return uh_check_launch("gate8_fwd");
+}
+
+static inline int gate8_blocks(long long Mp) {
+  long long b = (Mp + 255) / 256;
+  if (b > 512) b = 512;
+  return (int)b;
+}
+extern "C" int uh_gate8_parts(long long Mp) { return gate8_blocks(Mp); }
+
+// partial[blk][216] in the layout of wts: dW1 | dW2 | dW3 | db1 | db2 | db3
+__global__ __launch_bounds__(256) void gate8_bwd_kernel(long long Mp, const char* __restrict__ dout, int d_cs, int d_co,
+                                                        const char* __restrict__ g, int g_cs, int g_co,
+                                                        const char* __restrict__ x, int x_cs, int x_co,
+                                                        const float* __restrict__ wts, char* __restrict__ dg,
+                                                        int dg_cs, int dg_co, char* __restrict__ dx, int dx_cs,
+                                                        int dx_co, float* __restrict__ partial) {
+  __shared__ float w[G8_W];
+  __shared__ float red[4][G8_W];
+  for (int i = threadIdx.x; i < G8_W; i += 256) w[i] = wts[i];
+  __syncthreads();
+  float acc[G8_W];
+#pragma unroll
+  for (int i = 0; i < G8_W; ++i) acc[i] = 0.f;
+  for (long long m = (long long)blockIdx.x * 256 + threadIdx.x; m < Mp; m += (long long)gridDim.x * 256) {
+    float gv[8], xv[8], d[8], og[8], ox[8];
+    unpack8(*(const U4*)(g + (m * g_cs + g_co) * 2), gv);
+    unpack8(*(const U4*)(x + (m * x_cs + x_co) * 2), xv);
+    unpack8(*(const U4*)(dout + (m * d_cs + d_co) * 2), d);      // zero on pad rows
+#pragma unroll
+    for (int ci = 0; ci < 8; ++ci) og[ci] = ox[ci] = 0.f;
+#pragma unroll
+    for (int co = 0; co < 8; ++co) {
+      float z1 = w[192 + co], z2 = w[200 + co], z3 = w[208 + co];
+#pragma unroll
+      for (int ci = 0; ci < 8; ++ci) {
+        z1 += w[co * 8 + ci] * gv[ci];
+        z2 += w[64 + co * 8 + ci] * gv[ci];
+        z3 += w[128 + co * 8 + ci] * (gv[ci] + xv[ci]);
+      }
+      const float b = sigmoidf_(z1), c = tanhf(z2), a = sigmoidf_(z3);
+      const float dz1 = d[co] * c * b * (1.f - b);
+      const float dz2 = d[co] * b * (1.f - c * c);
+      const float dz3 = d[co] * xv[co] * a * (1.f - a);
+      ox[co] += d[co] * a;
+#pragma unroll
+      for (int ci = 0; ci < 8; ++ci) {
+        const float t = w[128 + co * 8 + ci] * dz3;
+        og[ci] += w[co * 8 + ci] * dz1 + w[64 + co * 8 + ci] * dz2 + t;
+        ox[ci] += t;
+        acc[co * 8 + ci] += dz1 * gv[ci];
+        acc[64 + co * 8 + ci] += dz2 * gv[ci];
+        acc[128 + co * 8 + ci] += dz3 * (gv[ci] + xv[ci]);
+      }
+      acc[192 + co] += dz1;
+      acc[200 + co] += dz2;
+      acc[208 + co] += dz3;
+    }
+    *(U4*)(dg + (m * dg_cs + dg_co) * 2) = pack8(og);
+    *(U4*)(dx + (m * dx_cs + dx_co) * 2) = pack8(ox);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < G8_W; ++i) {
+    const float v = wave_sum(acc[i]);
+    if (lane == 0) red[wave][i] = v;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < G8_W; i += 256)
+    partial[(long long)blockIdx.x * G8_W + i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+}
+
+extern "C" int uh_gate8_bwd(long long Mp, const void* dout, int d_cstride, int d_coff, const void* g, int g_cstride,
+                            int g_coff, const void* x, int x_cstride, int x_coff, const float* wts, void* dg,
+                            int dg_cstride, int dg_coff, void* dx, int dx_cstride, int dx_coff, float* partial,
+                            uh_stream s) {
+  UH_REQUIRE(Mp > 0 && dout && g && x && wts && dg && dx && partial, "gate8_bwd: bad arguments");
+  hipLaunchKernelGGL(gate8_bwd_kernel, dim3(gate8_blocks(Mp)), dim3(256), 0, (hipStream_t)s, Mp, (const char*)dout,
+                     d_cstride, d_coff, (const char*)g, g_cstride, g_coff, (const char*)x, x_cstride, x_coff, wts,
+                     (char*)dg, dg_cstride, dg_coff, (char*)dx, dx_cstride, dx_coff, partial);
+  return uh_check_launch("gate8_bwd");
+}
+
+// ---- NCHW fp32 image <-> 8-channel padded-linear bf16 (the top level of LUNeXt reads the image directly) ----------------
+__global__ __launch_bounds__(256) void nchw_to_c8_kernel(int B, int Cin, int H, int W, const float* __restrict__ x,
+                                                         char* __restrict__ out, int o_cs, int o_co) {
+  const int Wp = W + 1, Hp = H + 1;
+  const long long Mp = (long long)B * Hp * Wp;
+  for (long long m = (long long)blockIdx.x * 256 + threadIdx.x; m < Mp; m += (long long)gridDim.x * 256) {
+    const int px = (int)(m % Wp);
+    const long long r = m / Wp;
+    const int py = (int)(r % Hp);
+    const long long b = r / Hp;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (px < W && py < H)
+      for (int c = 0; c < Cin; ++c) v[c] = x[((b * Cin + c) * H + py) * W + px];
+    *(U4*)(out + (m * o_cs + o_co) * 2) = pack8(v);
+  }
+}
+
+extern "C" int uh_nchw_to_c8(int B, int Cin, int H, int W, const float* x, void* out, int o_cstride, int o_coff,
+                             uh_stream s) {
+  UH_REQUIRE(B > 0 && H > 0 && W > 0 && Cin >= 1 && Cin <= 8 && x && out, "nchw_to_c8: bad arguments (Cin<=8)");
+  const long long Mp = uh_mp(B, H, W);
+  long long blocks = (Mp + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(nchw_to_c8_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, B, Cin, H, W, x,
+                     (char*)out, o_cstride, o_coff);
+  return uh_check_launch("nchw_to_c8");
+}

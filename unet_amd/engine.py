@@ -279,7 +279,7 @@ class UNetRun:
         a = self.head_in
         fc = m.final_conv
         da = L.act(B, H, W, 64)
-        parts = _lib.lib.uh_head_bwd_parts(B, H, W)
+        parts = _lib.lib.uh_head_bwd_parts(B, H, W, 64)
         hp = L.f32(parts * oc * 65)
         call("uh_head_bwd", B, H, W, 64, oc, a.ptr, a.cstride, a.coff, fc.weight.data_ptr(), dl.data_ptr(),
              da.ptr, da.cstride, da.coff, hp.data_ptr(), s)

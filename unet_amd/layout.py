@@ -105,11 +105,13 @@ class Lease:
         self.held.append((key, t))
         return t
 
-    def act(self, B, H, W, C, cstride=None):
+    def act(self, B, H, W, C, cstride=None, tag=None):
+        """tag: a private sub-pool.  Buffers are zero when created and kernels only ever write the channels
+        of their view, so a tagged buffer whose upper channels are never written keeps them zero."""
         cstride = cstride or C
         guard = _lib_fn.uh_guard_rows(W)
         rows = guard * 2 + mp_rows(B, H, W)
-        key = ("act", B, H, W, cstride)
+        key = ("act", tag, B, H, W, cstride)
 
         def make():
             self.pool.bytes_allocated += rows * cstride * 2
@@ -126,12 +128,14 @@ class Lease:
 
         return self._take(key, make)
 
-    def bf16_flat(self, n):
-        key = ("bf16", n)
+    def bf16_flat(self, n, tag=None):
+        """tag: a private, zero-initialised sub-pool (packed weights with zero padding)."""
+        key = ("bf16", tag, n)
 
         def make():
             self.pool.bytes_allocated += n * 2
-            return torch.empty(n, dtype=torch.bfloat16, device=self.pool.device)
+            f = torch.empty if tag is None else torch.zeros
+            return f(n, dtype=torch.bfloat16, device=self.pool.device)
 
         return self._take(key, make)
 

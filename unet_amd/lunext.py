@@ -1,0 +1,482 @@
+"""Drop-in `LUNeXt` module (models/lunext.py:124-259 of the reference): same constructor, parameters,
+state_dict keys (176) and forward contract, executed by the HIP kernels of libunet_hip.so.
+
+Layout notes.  Activations are padded-linear NHWC bf16.  The full-resolution level works on
+`in_channels` (3) channels; it is carried zero-padded to 8 channels so that one pixel is one 16-byte
+access, with parameters zero-padded to match (a padded BatchNorm channel has gamma = 0 and therefore
+stays exactly zero).  The 2x2 stride-2 convolutions are space-to-depth + MFMA GEMM, the transposed
+convolutions MFMA GEMM + pixel-shuffle store, the gate's 1x1 convolutions MFMA GEMMs at C >= 64 and one
+fused vector kernel at the 8-channel level; GEMM operands narrower than 64 are zero-padded to 64.
+`att*.output_conv` is declared but never called by the reference (lunext.py:74,120): its parameters
+exist in the state_dict and receive no gradient, as there.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import call, EPI_RAW_STATS, EPI_AFFINE_RELU, EPI_MASKED, EPI_CONVT
+from .engine import BN_EPS, BN_MOMENTUM, _stream
+from .layout import pool_for
+
+L = _lib.lib
+
+
+def _padc(c):
+    return max(8, (c + 7) // 8 * 8)
+
+
+def _padv(t, n, fill=0.0):
+    if t.numel() == n:
+        return t.detach()
+    out = torch.full((n,), fill, dtype=torch.float32, device=t.device)
+    out[:t.numel()] = t.detach()
+    return out
+
+
+class _DWRec:
+    __slots__ = ("name", "x", "y", "a", "C", "Cp", "lvl", "w9", "mean", "invstd", "scale", "shift")
+
+
+class LUNeXtRun:
+    def __init__(self, module, x, training):
+        self.m, self.training, self.device = module, training, x.device
+        self.pool = pool_for(x.device)
+        self.lease = self.pool.lease()
+        B, Cin, H, W = x.shape
+        if H % 16 or W % 16:
+            raise NotImplementedError("LUNeXt kernels need H and W divisible by 16 (the reference's bilinear "
+                                      f"size-fix branch, lunext.py:225-251, is not built); got {H}x{W}")
+        if Cin != module.in_channels or Cin > 8:
+            raise ValueError(f"expected {module.in_channels} (<= 8) input channels, got {Cin}")
+        self.x = x
+        self.B = B
+        self.geo = [(B, H >> l, W >> l) for l in range(5)]
+        self.masks = [self.pool.rowmask(*g) for g in self.geo]
+        self.chans = [Cin, 64, 128, 256, 512]
+        self.cp = [_padc(c) for c in self.chans]
+        self.recs = {}
+        self.saved = {}
+
+    # ------------------------------------------------------------------ depthwise block
+    def _dw(self, name, x, lvl):
+        blk = getattr(self.m, name)
+        B, H, W = self.geo[lvl]
+        C, Cp = blk.depthwise.out_channels, x.C
+        s, Ls = _stream(), self.lease
+        w9 = Ls.f32(9 * Cp).view(9, Cp)
+        w9.zero_()
+        w9[:, :C] = blk.depthwise.weight.detach().view(C, 9).t()
+        bias = _padv(blk.depthwise.bias, Cp)
+        gamma, beta = _padv(blk.bn.weight, Cp), _padv(blk.bn.bias, Cp)
+        mask = self.masks[lvl]
+        a = Ls.act(B, H, W, Cp)
+        if not self.training:
+            rm, rv = _padv(blk.bn.running_mean, Cp), _padv(blk.bn.running_var, Cp, 1.0)
+            f = Ls.f32(2 * Cp)
+            call("uh_bn_fold_eval", Cp, gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(), None, BN_EPS,
+                 f[:Cp].data_ptr(), f[Cp:].data_ptr(), s)
+            call("uh_dwconv3x3_fwd", B, H, W, Cp, x.ptr, x.cstride, x.coff, w9.data_ptr(), bias.data_ptr(),
+                 EPI_AFFINE_RELU, f[:Cp].data_ptr(), f[Cp:].data_ptr(), mask.data_ptr(), a.ptr, a.cstride, a.coff,
+                 None, s)
+            return a
+        rec = _DWRec()
+        rec.name, rec.x, rec.a, rec.C, rec.Cp, rec.lvl, rec.w9 = name, x, a, C, Cp, lvl, w9
+        rec.y = Ls.act(B, H, W, Cp)
+        parts = L.uh_dw_parts(x.Mp, Cp)
+        stat = Ls.f32(parts * 2 * Cp)
+        call("uh_dwconv3x3_fwd", B, H, W, Cp, x.ptr, x.cstride, x.coff, w9.data_ptr(), bias.data_ptr(), EPI_RAW_STATS,
+             None, None, mask.data_ptr(), rec.y.ptr, rec.y.cstride, rec.y.coff, stat.data_ptr(), s)
+        f = Ls.f32(4 * Cp)
+        rec.mean, rec.invstd, rec.scale, rec.shift = f[:Cp], f[Cp:2 * Cp], f[2 * Cp:3 * Cp], f[3 * Cp:]
+        padded = Cp != C
+        rm = _padv(blk.bn.running_mean, Cp) if padded else blk.bn.running_mean
+        rv = _padv(blk.bn.running_var, Cp, 1.0) if padded else blk.bn.running_var
+        call("uh_bn_finalize", stat.data_ptr(), parts, Cp, B * H * W, gamma.data_ptr(), beta.data_ptr(), BN_EPS,
+             BN_MOMENTUM, rec.mean.data_ptr(), rec.invstd.data_ptr(), rec.scale.data_ptr(), rec.shift.data_ptr(),
+             rm.data_ptr(), rv.data_ptr(), blk.bn.num_batches_tracked.data_ptr(), s)
+        if padded:
+            blk.bn.running_mean.copy_(rm[:C])
+            blk.bn.running_var.copy_(rv[:C])
+        call("uh_bn_res_relu_apply", x.Mp, Cp, rec.y.ptr, rec.y.cstride, rec.y.coff, x.ptr, x.cstride, x.coff,
+             rec.scale.data_ptr(), rec.shift.data_ptr(), mask.data_ptr(), a.ptr, a.cstride, a.coff, s)
+        self.recs[name] = rec
+        return a
+
+    def _dw_backward(self, name, da, grads):
+        rec = self.recs[name]
+        B, H, W = self.geo[rec.lvl]
+        C, Cp, x, y = rec.C, rec.Cp, rec.x, rec.y
+        s, Ls = _stream(), self.lease
+        mask = self.masks[rec.lvl]
+        parts = L.uh_bn_bwd_parts(x.Mp, Cp)
+        partial = Ls.f32(parts * 2 * Cp)
+        st = (rec.mean.data_ptr(), rec.invstd.data_ptr(), rec.scale.data_ptr(), rec.shift.data_ptr())
+        call("uh_bn_res_relu_bwd_reduce", x.Mp, Cp, da.ptr, da.cstride, da.coff, y.ptr, y.cstride, y.coff, x.ptr,
+             x.cstride, x.coff, *st, partial.data_ptr(), s)
+        dg, db, coef = Ls.f32(Cp), Ls.f32(Cp), Ls.f32(2 * Cp)
+        call("uh_bn_bwd_finalize", partial.data_ptr(), parts, Cp, B * H * W, dg.data_ptr(), db.data_ptr(),
+             coef.data_ptr(), 0, s)
+        grads[name + ".bn.weight"], grads[name + ".bn.bias"] = dg[:C].clone(), db[:C].clone()
+        dy, dr = Ls.act(B, H, W, Cp), Ls.act(B, H, W, Cp)
+        call("uh_bn_res_relu_bwd_apply", x.Mp, Cp, da.ptr, da.cstride, da.coff, y.ptr, y.cstride, y.coff, x.ptr,
+             x.cstride, x.coff, *st, coef.data_ptr(), mask.data_ptr(), dy.ptr, dy.cstride, dy.coff, dr.ptr, dr.cstride,
+             dr.coff, s)
+        wparts = L.uh_dw_parts(x.Mp, Cp)
+        wp = Ls.f32(wparts * 9 * Cp)
+        call("uh_dwconv3x3_wgrad", B, H, W, Cp, dy.ptr, dy.cstride, dy.coff, x.ptr, x.cstride, x.coff, wp.data_ptr(), s)
+        w9g = Ls.f32(9 * Cp)
+        call("uh_colsum_finalize", wp.data_ptr(), wparts, 9 * Cp, 1, w9g.data_ptr(), 0, s)
+        grads[name + ".depthwise.weight"] = w9g.view(9, Cp)[:, :C].t().reshape(C, 1, 3, 3).contiguous()
+        # conv bias in front of train-mode BatchNorm: exactly zero gradient
+        grads[name + ".depthwise.bias"] = torch.zeros(C, dtype=torch.float32, device=self.device)
+        dx = Ls.act(B, H, W, Cp)
+        call("uh_dwconv3x3_dgrad", B, H, W, Cp, dy.ptr, dy.cstride, dy.coff, rec.w9.data_ptr(), dr.ptr, dr.cstride,
+             dr.coff, mask.data_ptr(), dx.ptr, dx.cstride, dx.coff, s)
+        return dx
+
+    # ------------------------------------------------------------------ 2x2 stride-2 conv (lunext.py:139-154)
+    def _down(self, l, x):
+        """level l-1 -> level l"""
+        conv = getattr(self.m, f"downconv{l}")
+        cin, cpi, cout = self.chans[l - 1], x.C, self.chans[l]
+        Bs, Hs, Ws = self.geo[l]
+        K = max(64, 4 * cpi)
+        s, Ls = _stream(), self.lease
+        x4 = Ls.act(Bs, Hs, Ws, K, tag=f"down{l}.x4")
+        call("uh_space_to_depth2", Bs, Hs, Ws, cpi, x.ptr, x.cstride, x.coff, x4.ptr, x4.cstride, 0, s)
+        wp = Ls.bf16_flat(cout * K, tag=f"down{l}.w")
+        call("uh_pack_weights", conv.weight.data_ptr(), wp.data_ptr(), cout, 4, cin, cin * 4, 1, 4, K, cpi, 0, s)
+        out = Ls.act(Bs, Hs, Ws, cout)
+        call("uh_conv_gemm", Bs, Hs, Ws, x4.ptr, x4.cstride, 0, K, wp.data_ptr(), cout, 1, EPI_MASKED, out.ptr,
+             out.cstride, out.coff, conv.bias.data_ptr(), None, None, None, self.masks[l].data_ptr(), s)
+        self.saved[f"down{l}"] = (x4, K, cpi)
+        return out
+
+    def _down_backward(self, l, dy, grads):
+        conv = getattr(self.m, f"downconv{l}")
+        x4, K, cpi = self.saved[f"down{l}"]
+        cin, cout = self.chans[l - 1], self.chans[l]
+        Bs, Hs, Ws = self.geo[l]
+        s, Ls = _stream(), self.lease
+        grads[f"downconv{l}.bias"] = self._colsum(dy, cout)
+        S = L.uh_conv_wgrad_splits(Bs, Hs, Ws, cout, K, 1)
+        part = Ls.f32(S * cout * K)
+        call("uh_conv_wgrad", Bs, Hs, Ws, dy.ptr, dy.cstride, dy.coff, cout, x4.ptr, x4.cstride, 0, K, 1,
+             part.data_ptr(), s)
+        dw = torch.empty_like(conv.weight)
+        call("uh_wgrad_reduce_strided", part.data_ptr(), S, cout * K, cout, 4, cin, K, cpi, cin * 4, 1, 4,
+             dw.data_ptr(), 0, s)
+        grads[f"downconv{l}.weight"] = dw
+        # dx4[m][t*cpi + ci] = sum_co dy[m][co] * W[co][ci][t]
+        wd = Ls.bf16_flat(K * cout, tag=f"down{l}.wd")
+        call("uh_pack_weights", conv.weight.data_ptr(), wd.data_ptr(), cin, 4, cout, 4, 1, cin * 4, cout, cpi * cout, 0, s)
+        dx4 = Ls.act(Bs, Hs, Ws, K)
+        call("uh_conv_gemm", Bs, Hs, Ws, dy.ptr, dy.cstride, dy.coff, cout, wd.data_ptr(), K, 1, EPI_MASKED, dx4.ptr,
+             dx4.cstride, 0, None, None, None, None, self.masks[l].data_ptr(), s)
+        B, H, W = self.geo[l - 1]
+        dx = Ls.act(B, H, W, cpi)
+        call("uh_depth_to_space2", Bs, Hs, Ws, cpi, dx4.ptr, dx4.cstride, 0, dx.ptr, dx.cstride, dx.coff, s)
+        return dx
+
+    # ------------------------------------------------------------------ transposed conv (lunext.py:161-179)
+    def _up(self, k, x):
+        """level 5-k -> level 4-k"""
+        l = 4 - k
+        up = getattr(self.m, f"upconv{k}")
+        cin, cout, cpo = self.chans[l + 1], self.chans[l], self.cp[l]
+        N = max(64, 4 * cpo)
+        Bs, Hs, Ws = self.geo[l + 1]
+        s, Ls = _stream(), self.lease
+        wp = Ls.bf16_flat(N * cin, tag=f"up{k}.w")
+        call("uh_pack_weights", up.weight.data_ptr(), wp.data_ptr(), cout, 4, cin, 4, 1, cout * 4, cin, cpo * cin, 0, s)
+        out = Ls.act(*self.geo[l], cpo)
+        bias = _padv(up.bias, cpo)
+        call("uh_conv_gemm", Bs, Hs, Ws, x.ptr, x.cstride, x.coff, cin, wp.data_ptr(), N, 1, EPI_CONVT, out.ptr,
+             out.cstride, out.coff, bias.data_ptr(), None, None, None, self.masks[l + 1].data_ptr(), s)
+        self.saved[f"up{k}"] = (x, N)
+        return out
+
+    def _up_backward(self, k, dup, grads):
+        l = 4 - k
+        up = getattr(self.m, f"upconv{k}")
+        x, N = self.saved[f"up{k}"]
+        cin, cout, cpo = self.chans[l + 1], self.chans[l], self.cp[l]
+        Bs, Hs, Ws = self.geo[l + 1]
+        s, Ls = _stream(), self.lease
+        grads[f"upconv{k}.bias"] = self._colsum(dup, cpo)[:cout].clone()
+        d4 = Ls.act(Bs, Hs, Ws, N, tag=f"up{k}.d4")
+        call("uh_space_to_depth2", Bs, Hs, Ws, cpo, dup.ptr, dup.cstride, dup.coff, d4.ptr, d4.cstride, 0, s)
+        S = L.uh_conv_wgrad_splits(Bs, Hs, Ws, N, cin, 1)
+        part = Ls.f32(S * N * cin)
+        call("uh_conv_wgrad", Bs, Hs, Ws, d4.ptr, d4.cstride, 0, N, x.ptr, x.cstride, x.coff, cin, 1, part.data_ptr(), s)
+        dw = torch.empty_like(up.weight)                       # [cin][cout][2][2]
+        call("uh_wgrad_reduce_strided", part.data_ptr(), S, N * cin, cout, 4, cin, cin, cpo * cin, 4, 1, cout * 4,
+             dw.data_ptr(), 0, s)
+        grads[f"upconv{k}.weight"] = dw
+        wd = Ls.bf16_flat(cin * N, tag=f"up{k}.wd")
+        call("uh_pack_weights", up.weight.data_ptr(), wd.data_ptr(), cin, 4, cout, cout * 4, 1, 4, N, cpo, 0, s)
+        dx = Ls.act(Bs, Hs, Ws, cin)
+        call("uh_conv_gemm", Bs, Hs, Ws, d4.ptr, d4.cstride, 0, N, wd.data_ptr(), cin, 1, EPI_MASKED, dx.ptr,
+             dx.cstride, dx.coff, None, None, None, None, self.masks[l + 1].data_ptr(), s)
+        return dx
+
+    def _colsum(self, a, C):
+        s, Ls = _stream(), self.lease
+        parts = L.uh_colsum_parts(a.Mp, C)
+        cp = Ls.f32(parts * C)
+        call("uh_colsum", a.Mp, C, a.ptr, a.cstride, a.coff, cp.data_ptr(), s)
+        out = torch.empty(C, dtype=torch.float32, device=self.device)
+        call("uh_colsum_finalize", cp.data_ptr(), parts, C, 1, out.data_ptr(), 0, s)
+        return out
+
+    # ------------------------------------------------------------------ attention gate (lunext.py:76-122)
+    def _gate(self, k, g, x):
+        att = getattr(self.m, f"att{k}")
+        l = 4 - k
+        B, H, W = self.geo[l]
+        C, Cp = self.chans[l], g.C
+        s, Ls = _stream(), self.lease
+        out = Ls.act(B, H, W, Cp)
+        if Cp == 8:
+            wts = Ls.f32(216)
+            wts.zero_()
+            for j, conv in enumerate((att.sigmoid_conv, att.tanh_conv, att.combine_conv)):
+                wts[64 * j:64 * j + 64].view(8, 8)[:C, :C] = conv.weight.detach().view(C, C)
+                wts[192 + 8 * j:192 + 8 * j + C] = conv.bias.detach()
+            call("uh_gate8_fwd", g.Mp, g.ptr, g.cstride, g.coff, x.ptr, x.cstride, x.coff, wts.data_ptr(),
+                 self.masks[l].data_ptr(), out.ptr, out.cstride, out.coff, s)
+            self.saved[f"att{k}"] = (g, x, wts)
+            return out
+        ssum = Ls.act(B, H, W, C)
+        call("uh_add", g.Mp, C, g.ptr, g.cstride, g.coff, x.ptr, x.cstride, x.coff, None, 0, 0, ssum.ptr, ssum.cstride,
+             ssum.coff, s)
+        w12 = Ls.bf16_flat(2 * C * C)
+        call("uh_pack_weights", att.sigmoid_conv.weight.data_ptr(), w12.data_ptr(), C, 1, C, C, 0, 1, C, 0, 0, s)
+        call("uh_pack_weights", att.tanh_conv.weight.data_ptr(), w12.data_ptr() + C * C * 2, C, 1, C, C, 0, 1, C, 0, 0, s)
+        w3 = Ls.bf16_flat(C * C)
+        call("uh_pack_weights", att.combine_conv.weight.data_ptr(), w3.data_ptr(), C, 1, C, C, 0, 1, C, 0, 0, s)
+        b12 = torch.cat([att.sigmoid_conv.bias.detach(), att.tanh_conv.bias.detach()])
+        z = Ls.act(B, H, W, 3 * C)
+        mask = self.masks[l]
+        call("uh_conv_gemm", B, H, W, g.ptr, g.cstride, g.coff, C, w12.data_ptr(), 2 * C, 1, EPI_MASKED, z.ptr,
+             z.cstride, 0, b12.data_ptr(), None, None, None, mask.data_ptr(), s)
+        call("uh_conv_gemm", B, H, W, ssum.ptr, ssum.cstride, ssum.coff, C, w3.data_ptr(), C, 1, EPI_MASKED, z.ptr,
+             z.cstride, 2 * C, att.combine_conv.bias.data_ptr(), None, None, None, mask.data_ptr(), s)
+        call("uh_gate_fwd", g.Mp, C, z.ptr, z.cstride, 0, x.ptr, x.cstride, x.coff, out.ptr, out.cstride, out.coff, s)
+        self.saved[f"att{k}"] = (g, x, ssum, z)
+        return out
+
+    def _gate_backward(self, k, dout, grads):
+        """returns (dg, dx)"""
+        att = getattr(self.m, f"att{k}")
+        l = 4 - k
+        B, H, W = self.geo[l]
+        C = self.chans[l]
+        s, Ls = _stream(), self.lease
+        pre = f"att{k}."
+        if self.cp[l] == 8 and C < 64:
+            g, x, wts = self.saved[f"att{k}"]
+            dg, dx = Ls.act(B, H, W, 8), Ls.act(B, H, W, 8)
+            parts = L.uh_gate8_parts(g.Mp)
+            part = Ls.f32(parts * 216)
+            call("uh_gate8_bwd", g.Mp, dout.ptr, dout.cstride, dout.coff, g.ptr, g.cstride, g.coff, x.ptr, x.cstride,
+                 x.coff, wts.data_ptr(), dg.ptr, dg.cstride, dg.coff, dx.ptr, dx.cstride, dx.coff, part.data_ptr(), s)
+            gw = Ls.f32(216)
+            call("uh_colsum_finalize", part.data_ptr(), parts, 216, 1, gw.data_ptr(), 0, s)
+            for j, nm in enumerate(("sigmoid_conv", "tanh_conv", "combine_conv")):
+                grads[pre + nm + ".weight"] = gw[64 * j:64 * j + 64].view(8, 8)[:C, :C].reshape(C, C, 1, 1).contiguous()
+                grads[pre + nm + ".bias"] = gw[192 + 8 * j:192 + 8 * j + C].clone()
+            return dg, dx
+        g, x, ssum, z = self.saved[f"att{k}"]
+        mask = self.masks[l]
+        dz, dxd = Ls.act(B, H, W, 3 * C), Ls.act(B, H, W, C)
+        call("uh_gate_bwd", g.Mp, C, dout.ptr, dout.cstride, dout.coff, z.ptr, z.cstride, 0, x.ptr, x.cstride, x.coff,
+             mask.data_ptr(), dz.ptr, dz.cstride, 0, dxd.ptr, dxd.cstride, dxd.coff, s)
+        db = self._colsum(dz, 3 * C)
+        for j, nm in enumerate(("sigmoid_conv", "tanh_conv", "combine_conv")):
+            grads[pre + nm + ".bias"] = db[j * C:(j + 1) * C].clone()
+        # weight gradients: [dW1; dW2] = dz[:, :2C]^T g,  dW3 = dz[:, 2C:]^T (g + x)
+        S = L.uh_conv_wgrad_splits(B, H, W, 2 * C, C, 1)
+        part = Ls.f32(S * 2 * C * C)
+        call("uh_conv_wgrad", B, H, W, dz.ptr, dz.cstride, 0, 2 * C, g.ptr, g.cstride, g.coff, C, 1, part.data_ptr(), s)
+        for j, nm in enumerate(("sigmoid_conv", "tanh_conv")):
+            dw = torch.empty(C, C, 1, 1, dtype=torch.float32, device=self.device)
+            call("uh_wgrad_reduce_strided", part.data_ptr() + j * C * C * 4, S, 2 * C * C, C, 1, C, C, 0, C, 0, 1,
+                 dw.data_ptr(), 0, s)
+            grads[pre + nm + ".weight"] = dw
+        S3 = L.uh_conv_wgrad_splits(B, H, W, C, C, 1)
+        part3 = Ls.f32(S3 * C * C)
+        call("uh_conv_wgrad", B, H, W, dz.ptr, dz.cstride, 2 * C, C, ssum.ptr, ssum.cstride, ssum.coff, C, 1,
+             part3.data_ptr(), s)
+        dw3 = torch.empty(C, C, 1, 1, dtype=torch.float32, device=self.device)
+        call("uh_wgrad_reduce", part3.data_ptr(), S3, C, 1, C, C, 0, C, 0, 1, dw3.data_ptr(), 0, s)
+        grads[pre + "combine_conv.weight"] = dw3
+        # input gradients: dg = sum_j dz_j W_j (one GEMM over K = 3C),  ds = dz_3 W_3,  dx = dout*a + ds
+        wd = Ls.bf16_flat(C * 3 * C)
+        for j, conv in enumerate((att.sigmoid_conv, att.tanh_conv, att.combine_conv)):
+            call("uh_pack_weights", conv.weight.data_ptr(), wd.data_ptr() + j * C * 2, C, 1, C, 1, 0, C, 3 * C, 0, 0, s)
+        dg = Ls.act(B, H, W, C)
+        call("uh_conv_gemm", B, H, W, dz.ptr, dz.cstride, 0, 3 * C, wd.data_ptr(), C, 1, EPI_MASKED, dg.ptr,
+             dg.cstride, dg.coff, None, None, None, None, mask.data_ptr(), s)
+        wd3 = Ls.bf16_flat(C * C)
+        call("uh_pack_weights", att.combine_conv.weight.data_ptr(), wd3.data_ptr(), C, 1, C, 1, 0, C, C, 0, 0, s)
+        ds = Ls.act(B, H, W, C)
+        call("uh_conv_gemm", B, H, W, dz.ptr, dz.cstride, 2 * C, C, wd3.data_ptr(), C, 1, EPI_MASKED, ds.ptr,
+             ds.cstride, ds.coff, None, None, None, None, mask.data_ptr(), s)
+        dx = Ls.act(B, H, W, C)
+        call("uh_add", g.Mp, C, dxd.ptr, dxd.cstride, dxd.coff, ds.ptr, ds.cstride, ds.coff, None, 0, 0, dx.ptr,
+             dx.cstride, dx.coff, s)
+        return dg, dx
+
+    # ------------------------------------------------------------------ whole network
+    def forward(self):
+        m, Ls, s = self.m, self.lease, _stream()
+        B, H, W = self.geo[0]
+        cin = self.chans[0]
+        cur = Ls.act(B, H, W, 8)
+        call("uh_nchw_to_c8", B, cin, H, W, self.x.data_ptr(), cur.ptr, cur.cstride, cur.coff, s)
+        skips = []
+        for l in range(1, 5):                                   # lunext.py:199-216
+            cur = self._dw(f"conv{l}_2", self._dw(f"conv{l}_1", cur, l - 1), l - 1)
+            skips.append(cur)
+            cur = self._down(l, cur)
+        cur = self._dw("conv5_2", self._dw("conv5_1", cur, 4), 4)
+        for k in range(1, 5):                                   # lunext.py:223-254
+            l = 4 - k
+            up = self._up(k, cur)
+            cur = self._gate(k, up, skips[l])
+            cur = self._dw(f"conv_up{k}_2", self._dw(f"conv_up{k}_1", cur, l), l)
+        oc = m.out_channels
+        fc = m.final_conv
+        w = torch.zeros(oc, 8, dtype=torch.float32, device=self.device)
+        w[:, :cin] = fc.weight.detach().view(oc, cin)
+        logits = torch.empty(B, oc, H, W, dtype=torch.float32, device=self.device)
+        call("uh_head_fwd", B, H, W, 8, oc, cur.ptr, cur.cstride, cur.coff, w.data_ptr(), fc.bias.data_ptr(),
+             logits.data_ptr(), s)
+        self.head_in, self.head_w = cur, w
+        return logits
+
+    def backward(self, dlogits):
+        if not self.training:
+            raise RuntimeError("backward through an eval-mode forward is not built; call model.train() first")
+        m, Ls, s = self.m, self.lease, _stream()
+        grads = {}
+        B, H, W = self.geo[0]
+        cin, oc = self.chans[0], m.out_channels
+        dl = dlogits.contiguous().float()
+        a = self.head_in
+        da = Ls.act(B, H, W, 8)
+        parts = L.uh_head_bwd_parts(B, H, W, 8)
+        hp = Ls.f32(parts * oc * 9)
+        call("uh_head_bwd", B, H, W, 8, oc, a.ptr, a.cstride, a.coff, self.head_w.data_ptr(), dl.data_ptr(), da.ptr,
+             da.cstride, da.coff, hp.data_ptr(), s)
+        hw = Ls.f32(oc * 9)
+        call("uh_colsum_finalize", hp.data_ptr(), parts, oc * 9, 1, hw.data_ptr(), 0, s)
+        hw = hw.view(oc, 9)
+        grads["final_conv.weight"] = hw[:, :cin].reshape(oc, cin, 1, 1).clone()
+        grads["final_conv.bias"] = hw[:, 8].clone()
+        skip_grads = [None] * 4
+        for k in range(4, 0, -1):
+            l = 4 - k
+            da = self._dw_backward(f"conv_up{k}_1", self._dw_backward(f"conv_up{k}_2", da, grads), grads)
+            dg, dx = self._gate_backward(k, da, grads)
+            skip_grads[l] = dx
+            da = self._up_backward(k, dg, grads)
+        da = self._dw_backward("conv5_1", self._dw_backward("conv5_2", da, grads), grads)
+        for l in range(4, 0, -1):
+            dpool = self._down_backward(l, da, grads)
+            Bl, Hl, Wl = self.geo[l - 1]
+            C = self.cp[l - 1]
+            sg = skip_grads[l - 1]
+            tot = Ls.act(Bl, Hl, Wl, C)
+            call("uh_add", tot.Mp, C, dpool.ptr, dpool.cstride, dpool.coff, sg.ptr, sg.cstride, sg.coff, None, 0, 0,
+                 tot.ptr, tot.cstride, tot.coff, s)
+            da = self._dw_backward(f"conv{l}_1", self._dw_backward(f"conv{l}_2", tot, grads), grads)
+        return grads
+
+    def release(self):
+        self.recs, self.saved = {}, {}
+        self.lease.release()
+
+
+class _LUNeXtFn(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, module, x, *params):
+        run = LUNeXtRun(module, x, training=True)
+        logits = run.forward()
+        ctx.run = run
+        ctx.names = [n for n, _ in module.named_parameters()]
+        return logits
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dlogits):
+        run = ctx.run
+        if run is None:
+            raise RuntimeError("the buffers of this forward pass were already released (second backward?)")
+        if ctx.needs_input_grad[1]:
+            raise NotImplementedError("gradient with respect to the input image is not built")
+        grads = run.backward(dlogits)
+        run.release()
+        ctx.run = None
+        out = [None, None]
+        for i, n in enumerate(ctx.names):
+            out.append(grads.get(n) if ctx.needs_input_grad[2 + i] else None)   # att*.output_conv.*: None
+        return tuple(out)
+
+
+class _DWParams(nn.Module):
+    """Parameter container with the keys of DepthwiseConvBlock (lunext.py:14-16)."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.depthwise = nn.Conv2d(c, c, kernel_size=3, padding=1, groups=c)
+        self.bn = nn.BatchNorm2d(c)
+
+
+class _GateParams(nn.Module):
+    """Parameter container with the keys of AttentionGate (lunext.py:67-74)."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.sigmoid_conv = nn.Conv2d(c, c, kernel_size=1, bias=True)
+        self.tanh_conv = nn.Conv2d(c, c, kernel_size=1, bias=True)
+        self.combine_conv = nn.Conv2d(c, c, kernel_size=1, bias=True)
+        self.output_conv = nn.Conv2d(c, c, kernel_size=1, bias=True)
+
+
+class LUNeXt(nn.Module):
+    def __init__(self, in_channels=3, out_channels=1):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        ch = [in_channels, 64, 128, 256, 512]
+        for l in range(1, 5):                                   # lunext.py:137-154
+            setattr(self, f"conv{l}_1", _DWParams(ch[l - 1]))
+            setattr(self, f"conv{l}_2", _DWParams(ch[l - 1]))
+            setattr(self, f"downconv{l}", nn.Conv2d(ch[l - 1], ch[l], kernel_size=2, stride=2))
+        self.conv5_1 = _DWParams(512)
+        self.conv5_2 = _DWParams(512)
+        for k in range(1, 5):                                   # lunext.py:161-182
+            ci, co = ch[5 - k], ch[4 - k]
+            setattr(self, f"upconv{k}", nn.ConvTranspose2d(ci, co, kernel_size=2, stride=2))
+            setattr(self, f"att{k}", _GateParams(co))
+            setattr(self, f"conv_up{k}_1", _DWParams(co))
+            setattr(self, f"conv_up{k}_2", _DWParams(co))
+        self.final_conv = nn.Conv2d(in_channels, out_channels, kernel_size=1)
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("unet_amd.LUNeXt runs on the HIP kernels only: move the model and the input to a "
+                               "ROCm device (there is no CPU path)")
+        if x.dim() != 4:
+            raise ValueError(f"expected a [B,C,H,W] tensor, got shape {tuple(x.shape)}")
+        params = list(self.parameters())
+        need_grad = torch.is_grad_enabled() and self.training and any(p.requires_grad for p in params)
+        if need_grad:
+            return _LUNeXtFn.apply(self, x.float().contiguous(), *params)
+        with torch.no_grad():
+            run = LUNeXtRun(self, x.detach().float().contiguous(), training=self.training)
+            logits = run.forward()
+            run.release()
+        return logits
