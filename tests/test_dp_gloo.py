@@ -1,0 +1,95 @@
+"""Data-parallel path on CPU, world_size 2, gloo backend: the bucket layout, the order in which gradients become
+ready, the asynchronous bucketed all-reduce and the 1/world scaling of unet_amd.dp, driven by gradients that the
+CPU oracle computes per shard (the HIP kernels need a GPU; everything around them does not).
+Checked property (DDP semantics): after the step every rank holds the MEAN of the per-shard gradients."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+from oracle import ref_cpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    import unet_amd
+    from unet_amd.dp import DataParallelTrainer, backward_param_order
+    torch.manual_seed(100 + rank)                 # different initial weights per rank: the trainer must broadcast rank 0's
+    model = unet_amd.UNet(3, 1)                   # parameter container only; no forward on CPU
+    trainer = DataParallelTrainer(model, lr=1e-3, bucket_bytes=8 << 20)
+    assert trainer.world == world and len(trainer.buckets.buckets) >= 4
+    ref = ref_cpu.RefUNet(3, 1)
+    ref.load_state_dict(model.state_dict())       # weights after the broadcast
+    x, m = ref_cpu.synth_batch(2 * world, 3, 16, 16)
+    idx = DataParallelTrainer.shard(2 * world, epoch=0, rank=rank, world=world)
+    loss = nn.BCEWithLogitsLoss()(ref.train()(x[idx]), m[idx])
+    (loss / world).backward()                     # the trainer seeds backward with d(loss/world)
+    # play the backward pass: gradients appear last layer first, into the bucket views
+    trainer.buckets.reset()
+    for name in backward_param_order(model):
+        trainer.buckets.views[name].copy_(dict(ref.named_parameters())[name].grad)
+        trainer._on_ready((name,))
+    for b in trainer.buckets.buckets:
+        w = b.pop("work", None)
+        assert w is not None, "every bucket must have been reduced"
+        w.wait()
+    flat = trainer.buckets.flat.clone()
+    assert all(p.grad.data_ptr() == trainer.buckets.views[n].data_ptr() for n, p in model.named_parameters())
+    torch.save({"flat": flat, "idx": idx, "w0": model.conv1_1.weight.detach().clone()},
+               os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_bucketed_allreduce_world2(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(os.path.join(tmp_path, f"rank{i}.pt"), weights_only=True) for i in range(world)]
+    assert torch.equal(r[0]["flat"], r[1]["flat"]), "ranks disagree after all-reduce"
+    assert torch.equal(r[0]["w0"], r[1]["w0"]), "initial weights were not broadcast"
+    assert sorted(torch.cat([r[0]["idx"], r[1]["idx"]]).tolist()) == list(range(2 * world)), "shards must partition"
+    # single-process answer: mean over shards of the per-shard gradients
+    import unet_amd
+    from unet_amd.dp import backward_param_order
+    torch.manual_seed(100)
+    model = unet_amd.UNet(3, 1)                   # rank 0's weights
+    ref = ref_cpu.RefUNet(3, 1)
+    ref.load_state_dict(model.state_dict())
+    assert torch.equal(ref.conv1_1.weight, r[0]["w0"])
+    x, m = ref_cpu.synth_batch(2 * world, 3, 16, 16)
+    want = None
+    for i in range(world):
+        ref.zero_grad()
+        nn.BCEWithLogitsLoss()(ref.train()(x[r[i]["idx"]]), m[r[i]["idx"]]).backward()
+        g = torch.cat([dict(ref.named_parameters())[n].grad.flatten() for n in backward_param_order(model)])
+        want = g / world if want is None else want + g / world
+    torch.testing.assert_close(r[0]["flat"], want, rtol=1e-5, atol=1e-7)
+
+
+def test_bucket_layout():
+    import unet_amd
+    from unet_amd.dp import GradBuckets, backward_param_order
+    model = unet_amd.UNet(3, 1)
+    order = backward_param_order(model)
+    assert order[0] == "final_conv.weight" and order[-1] == "conv1_1.bias" and len(order) == 82
+    b = GradBuckets(model, bucket_bytes=25 << 20)
+    assert sum(x["tensor"].numel() for x in b.buckets) == 31043521      # every parameter exactly once
+    assert all(x["tensor"].numel() * 4 >= (25 << 20) for x in b.buckets[:-1])
+    # buckets are contiguous slices in backward order
+    off = 0
+    for x in b.buckets:
+        assert x["tensor"].data_ptr() == b.flat.data_ptr() + off * 4
+        off += x["tensor"].numel()
