@@ -233,11 +233,246 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmArgs p) {
   }
 }
 
-static bool use_wide_m(int N) { return N % 128 != 0; }  // N = 64, 192, ...: 256x64 tiles
+// ===================================================================================================
+// 3x3 "band" kernel: the workhorse for T = 9.
+//
+// Measured on MI355X the tile kernel above is bound by the global->LDS path (staging alone takes 80-97 %
+// of its time, ~15 TB/s of LDS-DMA traffic chip-wide), so this kernel spends fewer staged bytes per FLOP:
+//   * the three taps of one filter row (kx = 0,1,2) read the SAME activation rows shifted by one, so one
+//     staged band of BM+2 rows serves three taps (A bytes / 3);
+//   * tiles are 256x128 or 512x64 with eight waves, each wave 64x64 (B bytes / 2 or A-per-FLOP halved);
+//   * K is consumed 32 channels at a time so that three stages (A band + 3 weight taps each) fit in LDS
+//     as a ring: while one stage feeds the MFMAs two more are in flight behind a counted s_waitcnt, and
+//     there is one raw s_barrier per stage.
+// LDS rows are 64 B; chunk c of row r sits at position c ^ ((r>>1)&2), which keeps ds_read_b128 fragment
+// reads conflict-free for every row shift (checked exhaustively against the gfx950 lane groups).
+// Workgroup ids are remapped so that each XCD's L2 sees a contiguous range of M tiles (neighbouring
+// tiles share two of their three bands).
+template <int BM, int BN>
+struct BandCfg {
+  static constexpr int WN = BN / 64;
+  static constexpr int WM = 8 / WN;
+  static_assert(BM == WM * 64, "each of the eight waves owns 64 rows");
+  static constexpr int AG = BM / 16 + 1;          // 1 KiB groups (16 rows x 64 B) of the A band: BM+16 >= BM+2 rows
+  static constexpr int BGT = BN / 16;             // groups per weight tap
+  static constexpr int SG = AG + 3 * BGT;         // groups per stage
+  static constexpr int STAGE = SG * 1024;
+  static constexpr int NSTAGE = 3;
+  static constexpr int LDS_BYTES = NSTAGE * STAGE;
+  static constexpr int PITCH = BN * 2 + 16;
+  static constexpr int FLAG_OFF = BM * PITCH;
+  static constexpr int RED_OFF = FLAG_OFF + BM * 4;
+  static constexpr int EPI_BYTES = RED_OFF + WM * 2 * BN * 4;
+  static_assert(EPI_BYTES <= LDS_BYTES, "epilogue reuses the staging LDS");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
 
+template <int BM, int BN>
+__global__ __launch_bounds__(512, 2) void conv_band_kernel(GemmArgs p, int ntm, int tiles_per_xcd) {
+  using C = BandCfg<BM, BN>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // XCD-aware remap: workgroups b and b+8 share an L2; give each L2 a contiguous run of M tiles
+  const int tile = (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
+  if (tile >= ntm) return;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / C::WN, wn = wave % C::WN;
+  const long long m0 = (long long)tile * BM;
+  const int n0 = blockIdx.y * BN;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int KC = p.K / 32;
+
+  // ---- staging: one wave instruction = 16 rows x 64 B; lane -> (row lane/4, position lane%4) ----------
+  const int srow = lane >> 2;
+  const int src_chunk = (lane & 3) ^ ((srow >> 1) & 2);
+  const long long a_row_bytes = (long long)p.a_cstride * 2;
+  const long long b_row_bytes = 9LL * p.K * 2;
+  const char* a_lane = p.A + (m0 - 1 + srow) * a_row_bytes + (long long)p.a_coff * 2 + src_chunk * 16;
+  const char* b_lane = p.Wt + (long long)(n0 + srow) * b_row_bytes + src_chunk * 16;
+  const int my_groups = (C::SG - wave + 7) / 8;     // groups wave, wave+8, ... < SG
+
+  auto stage = [&](int buf, int ky, int kc) {
+    const char* as = a_lane + (long long)(ky - 1) * p.Wp * a_row_bytes + kc * 64;
+    const char* bs = b_lane + ((long long)ky * 3 * p.K + kc * 32) * 2;
+    char* lds = smem + buf * C::STAGE;
+#pragma unroll
+    for (int q = 0; q < (C::SG + 7) / 8; ++q) {
+      const int gi = wave + 8 * q;
+      if (gi < C::SG) {
+        const char* src;
+        if (gi < C::AG) {
+          src = as + (long long)gi * 16 * a_row_bytes;
+        } else {
+          const int j = gi - C::AG;
+          const int kx = j / C::BGT, nb = j % C::BGT;
+          src = bs + (long long)kx * p.K * 2 + (long long)nb * 16 * b_row_bytes;
+        }
+        __builtin_amdgcn_global_load_lds((const UH_GLOBAL void*)src, (UH_LDS void*)(lds + gi * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  // ---- fragment read offsets (bytes inside a stage) -----------------------------------------------------
+  int a_off[3];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx) {
+    const int r = l15 + kx;
+    a_off[kx] = (wm * 64 + r) * 64 + ((g ^ ((r >> 1) & 2)) << 4);
+  }
+  const int b_off = C::AG * 1024 + (wn * 64 + l15) * 64 + ((g ^ ((l15 >> 1) & 2)) << 4);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int niter = 3 * KC;
+  // prologue: two stages in flight
+  stage(0, 0, 0);
+  int ky_n = 0, kc_n = 1;                       // coordinates of the next stage to issue
+  if (kc_n == KC) { kc_n = 0; ++ky_n; }
+  if (niter > 1) {
+    stage(1, ky_n, kc_n);
+    if (++kc_n == KC) { kc_n = 0; ++ky_n; }
+  }
+  int buf = 0;
+  for (int it = 0; it < niter; ++it) {
+    // wait for this wave's loads of stage `it`, leaving the next stage's loads in flight
+    if (it + 1 < niter) {
+      if (my_groups == (C::SG + 7) / 8)
+        __builtin_amdgcn_s_waitcnt(0x0F70 | (((C::SG + 7) / 8) & 0xF) | ((((C::SG + 7) / 8) >> 4) << 14));
+      else
+        __builtin_amdgcn_s_waitcnt(0x0F70 | (((C::SG + 7) / 8 - 1) & 0xF) | ((((C::SG + 7) / 8 - 1) >> 4) << 14));
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();               // stage `it` complete for every wave; stage it-1 fully consumed
+    asm volatile("" ::: "memory");
+    if (it + 2 < niter) {
+      int nb = buf + 2;
+      if (nb >= 3) nb -= 3;
+      stage(nb, ky_n, kc_n);
+      if (++kc_n == KC) { kc_n = 0; ++ky_n; }
+    }
+    const char* S = smem + buf * C::STAGE;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(S + a_off[kx] + i * 1024);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(S + b_off + kx * (BN * 64) + j * 1024);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    if (++buf == 3) buf = 0;
+  }
+
+  // ---- epilogue (same contract as conv_gemm_kernel) ---------------------------------------------------------
+  __syncthreads();
+  float* flag = (float*)(smem + C::FLAG_OFF);
+  float* red = (float*)(smem + C::RED_OFF);
+  for (int i = tid; i < BM; i += 512) {
+    const long long m = m0 + i;
+    flag[i] = (m < p.Mp && p.rowmask[m]) ? 1.f : 0.f;
+  }
+  __syncthreads();
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int col = wn * 64 + j * 16 + l15;
+    const int n = n0 + col;
+    float bias = 0.f, sc = 1.f, sh = 0.f;
+    if (p.mode == UH_EPI_AFFINE_RELU) {
+      sc = p.scale[n];
+      sh = p.shift[n];
+    } else {
+      bias = p.bias ? p.bias[n] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rbase = wm * 64 + i * 16 + g * 4;
+      const f32x4 f = *(const f32x4*)(flag + rbase);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = acc[i][j][e];
+        if (p.mode == UH_EPI_AFFINE_RELU) {
+          v = fmaxf(v * sc + sh, 0.f);
+        } else {
+          v += bias;
+        }
+        v *= f[e];
+        if (p.mode == UH_EPI_RAW_STATS) {
+          s1[j] += v;
+          s2[j] += v * v;
+          *(_Float16*)(smem + (rbase + e) * C::PITCH + col * 2) = f2h(v);
+        } else {
+          *(bf16*)(smem + (rbase + e) * C::PITCH + col * 2) = f2bf(v);
+        }
+      }
+    }
+  }
+  if (p.mode == UH_EPI_RAW_STATS) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      s1[j] += __shfl_xor(s1[j], 16, 64);
+      s1[j] += __shfl_xor(s1[j], 32, 64);
+      s2[j] += __shfl_xor(s2[j], 16, 64);
+      s2[j] += __shfl_xor(s2[j], 32, 64);
+      if (g == 0) {
+        const int col = wn * 64 + j * 16 + l15;
+        red[(wm * 2 + 0) * BN + col] = s1[j];
+        red[(wm * 2 + 1) * BN + col] = s2[j];
+      }
+    }
+  }
+  __syncthreads();
+  if (p.mode == UH_EPI_RAW_STATS && tid < 2 * BN) {
+    const int which = tid / BN, col = tid % BN;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < C::WM; ++w) v += red[(w * 2 + which) * BN + col];
+    p.stat_partial[((long long)tile * 2 + which) * p.N + n0 + col] = v;
+  }
+  constexpr int CPR = BN / 8;
+#pragma unroll
+  for (int q = tid; q < BM * CPR; q += 512) {
+    const int row = q / CPR, cc = q % CPR;
+    const long long m = m0 + row;
+    if (m < p.Mp) {
+      const U4 v = *(const U4*)(smem + row * C::PITCH + cc * 16);
+      *(U4*)(p.out + (m * p.o_cstride + p.o_coff + n0 + cc * 8) * 2) = v;
+    }
+  }
+}
+
+template <int BM, int BN>
+static void launch_band(const GemmArgs& p, hipStream_t st) {
+  using C = BandCfg<BM, BN>;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)conv_band_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    attr = true;
+  }
+  const int ntm = (int)((p.Mp + BM - 1) / BM);
+  const int tpx = (ntm + 7) / 8;
+  dim3 grid(8 * tpx, p.N / BN);
+  hipLaunchKernelGGL((conv_band_kernel<BM, BN>), grid, dim3(512), C::LDS_BYTES, st, p, ntm, tpx);
+}
+
+static bool use_wide_m(int N) { return N % 128 != 0; }  // N = 64, 192, ...: tiles 64 wide
+
+// M tiles of the T = 9 path (rows of stat_partial in RAW_STATS mode)
 extern "C" int uh_conv_gemm_mtiles(int B, int H, int W, int N) {
   const long long Mp = uh_mp(B, H, W);
-  return (int)((Mp + (use_wide_m(N) ? 255 : 127)) / (use_wide_m(N) ? 256 : 128));
+  const int bm = use_wide_m(N) ? 512 : 256;
+  return (int)((Mp + bm - 1) / bm);
 }
 
 extern "C" int uh_conv_gemm(int B, int H, int W, const void* a, int a_cstride, int a_coff, int K,
@@ -286,7 +521,12 @@ extern "C" int uh_conv_gemm(int B, int H, int W, const void* a, int a_cstride, i
   // transposed conv: Cout = N/4, or the width of the output window when that is narrower (N zero-padded to 64)
   p.Cout = (mode == UH_EPI_CONVT) ? ((N / 4 < o_cstride - o_coff) ? N / 4 : o_cstride - o_coff) : N;
   hipStream_t st = (hipStream_t)s;
-  if (use_wide_m(N)) {
+  if (T == 9) {
+    if (use_wide_m(N))
+      launch_band<512, 64>(p, st);
+    else
+      launch_band<256, 128>(p, st);
+  } else if (use_wide_m(N)) {
     using C = Cfg<256, 64>;
     static bool attr = false;
     if (!attr) {

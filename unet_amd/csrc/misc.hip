@@ -23,9 +23,9 @@ int uh_check_launch(const char* what) {
 
 extern "C" const char* uh_last_error(void) { return g_err; }
 extern "C" int uh_version(void) { return 1; }
-// (W+1)+1 rows cover the 3x3 neighbourhood of the first/last row; 256 more cover the overhang
-// of the last M tile (tiles are at most 256 rows) and of the last 128-row wgrad stage.
-extern "C" int uh_guard_rows(int W) { return W + 2 + 256 + 8; }
+// (W+1)+1 rows cover the 3x3 neighbourhood of the first/last row; 512+16 more cover the overhang
+// of the last M tile (tiles are at most 512 rows, bands 16 rows longer) and of the last wgrad stage.
+extern "C" int uh_guard_rows(int W) { return W + 2 + 512 + 32; }
 
 __global__ void rowmask_kernel(int H, int W, long long Mp, uint8_t* mask) {
   const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
