@@ -237,17 +237,24 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmArgs p) {
 // 3x3 "band" kernel: the workhorse for T = 9.
 //
 // Measured on MI355X the tile kernel above is bound by the global->LDS path (staging alone takes 80-97 %
-// of its time, ~15 TB/s of LDS-DMA traffic chip-wide), so this kernel spends fewer staged bytes per FLOP:
-//   * the three taps of one filter row (kx = 0,1,2) read the SAME activation rows shifted by one, so one
-//     staged band of BM+2 rows serves three taps (A bytes / 3);
-//   * tiles are 256x128 or 512x64 with eight waves, each wave 64x64 (B bytes / 2 or A-per-FLOP halved);
-//   * K is consumed 32 channels at a time so that three stages (A band + 3 weight taps each) fit in LDS
-//     as a ring: while one stage feeds the MFMAs two more are in flight behind a counted s_waitcnt, and
-//     there is one raw s_barrier per stage.
+// of its time), and its per-tile prologue and LDS-transposing epilogue are exposed.  This kernel
+//   * stages fewer bytes per FLOP: the three taps of one filter row (kx = 0,1,2) read the SAME activation
+//     rows shifted by one, so one staged band of BM+2 rows serves three taps; tiles are 256x128 or 512x64
+//     with eight waves of 64x64;
+//   * consumes K 32 channels at a time through a three-stage LDS ring (A band + 3 weight taps per stage)
+//     behind counted s_waitcnt and raw s_barriers, with the two waves of every SIMD alternating between a
+//     load part and an MFMA part (see the main loop);
+//   * is persistent: one workgroup per CU walks a list of M tiles and the ring runs on across tile
+//     boundaries, so the next tile's first stages are already in LDS while this tile's results are stored;
+//   * stores straight from the accumulators: the weight rows are staged in permuted order (LDS row
+//     16*j + c holds output channel 4*c + j of the wave's 64), so the four accumulator tiles a lane holds
+//     for one activation row are four ADJACENT channels -> one 8-byte store per row, 16 lanes = one
+//     128-byte line.  BatchNorm partial sums are reduced across waves through a small LDS array that is
+//     flushed to global memory a few barriers later, from inside the next tile.
 // LDS rows are 64 B; chunk c of row r sits at position c ^ ((r>>1)&2), which keeps ds_read_b128 fragment
 // reads conflict-free for every row shift (checked exhaustively against the gfx950 lane groups).
-// Workgroup ids are remapped so that each XCD's L2 sees a contiguous range of M tiles (neighbouring
-// tiles share two of their three bands).
+// Workgroups b, b+8, ... share an XCD; each XCD walks one contiguous range of M tiles so that the band
+// rows neighbouring tiles share, and the A rows that all N tiles share, hit in its L2.
 template <int BM, int BN>
 struct BandCfg {
   static constexpr int WN = BN / 64;
@@ -258,59 +265,68 @@ struct BandCfg {
   static constexpr int SG = AG + 3 * BGT;         // groups per stage
   static constexpr int STAGE = SG * 1024;
   static constexpr int NSTAGE = 3;
-  static constexpr int LDS_BYTES = NSTAGE * STAGE;
-  static constexpr int PITCH = BN * 2 + 16;
-  static constexpr int FLAG_OFF = BM * PITCH;
-  static constexpr int RED_OFF = FLAG_OFF + BM * 4;
-  static constexpr int EPI_BYTES = RED_OFF + WM * 2 * BN * 4;
-  static_assert(EPI_BYTES <= LDS_BYTES, "epilogue reuses the staging LDS");
+  static constexpr int FLAG_OFF = NSTAGE * STAGE;             // 8 waves x 64 dwords of row flags
+  static constexpr int RED_OFF = FLAG_OFF + 8 * 256;          // float[WM][2][BN]
+  static constexpr int LDS_BYTES = RED_OFF + WM * 2 * BN * 4;
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
-template <int BM, int BN>
-__global__ __launch_bounds__(512, 2) void conv_band_kernel(GemmArgs p, int ntm, int tiles_per_xcd) {
+template <int BM, int BN, int MODE>
+__global__ __launch_bounds__(512) void conv_band_kernel(GemmArgs p, int ntm, int tiles_per_xcd) {
   using C = BandCfg<BM, BN>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // XCD-aware remap: workgroups b and b+8 share an L2; give each L2 a contiguous run of M tiles
-  const int tile = (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
-  if (tile >= ntm) return;
+  // this workgroup's tiles: t_first, t_first + wstep, ... < t_end
+  const int xcd = blockIdx.x & 7;
+  const int wstep = gridDim.x >> 3;
+  const int t_first = xcd * tiles_per_xcd + (blockIdx.x >> 3);
+  const int t_end = min((xcd + 1) * tiles_per_xcd, ntm);
+  if (t_first >= t_end) return;
+  const int my_tiles = (t_end - t_first + wstep - 1) / wstep;
+
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / C::WN, wn = wave % C::WN;
-  const long long m0 = (long long)tile * BM;
   const int n0 = blockIdx.y * BN;
   const int l15 = lane & 15, g = lane >> 4;
   const int KC = p.K / 32;
 
   // ---- staging: one wave instruction = 16 rows x 64 B; lane -> (row lane/4, position lane%4) ----------
+  // A stage is SG groups; wave w stages groups w, w+8, ... ("slots" q = 0..5; only slot 5 can be absent).
+  // Slot pointers are fixed up front; a stage adds one of two wave-uniform offsets (activation / weight).
+  constexpr int NQ = 6;
+  static_assert((C::SG + 7) / 8 == NQ, "six staging slots per wave");
   const int srow = lane >> 2;
   const int src_chunk = (lane & 3) ^ ((srow >> 1) & 2);
   const long long a_row_bytes = (long long)p.a_cstride * 2;
   const long long b_row_bytes = 9LL * p.K * 2;
-  const char* a_lane = p.A + (m0 - 1 + srow) * a_row_bytes + (long long)p.a_coff * 2 + src_chunk * 16;
-  const char* b_lane = p.Wt + (long long)(n0 + srow) * b_row_bytes + src_chunk * 16;
-  const int my_groups = (C::SG - wave + 7) / 8;     // groups wave, wave+8, ... < SG
-
-  auto stage = [&](int buf, int ky, int kc) {
-    const char* as = a_lane + (long long)(ky - 1) * p.Wp * a_row_bytes + kc * 64;
-    const char* bs = b_lane + ((long long)ky * 3 * p.K + kc * 32) * 2;
-    char* lds = smem + buf * C::STAGE;
+  const char* gp[NQ];
+  bool slot_is_a[NQ];
 #pragma unroll
-    for (int q = 0; q < (C::SG + 7) / 8; ++q) {
-      const int gi = wave + 8 * q;
-      if (gi < C::SG) {
-        const char* src;
-        if (gi < C::AG) {
-          src = as + (long long)gi * 16 * a_row_bytes;
-        } else {
-          const int j = gi - C::AG;
-          const int kx = j / C::BGT, nb = j % C::BGT;
-          src = bs + (long long)kx * p.K * 2 + (long long)nb * 16 * b_row_bytes;
-        }
-        __builtin_amdgcn_global_load_lds((const UH_GLOBAL void*)src, (UH_LDS void*)(lds + gi * 1024), 16, 0, 0);
-      }
-    }
+  for (int q = 0; q < NQ; ++q) {
+    const int gi = wave + 8 * q;
+    slot_is_a[q] = gi < C::AG;
+    const int j = gi - C::AG;
+    const int kx = j / C::BGT, nb = j % C::BGT;
+    // weight group nb = LDS rows 16*nb .. 16*nb+15 of the tap = accumulator tile (nb%4) of wave column nb/4
+    const int chan = (nb >> 2) * 64 + srow * 4 + (nb & 3);
+    const char* pa = p.A + (srow + (long long)gi * 16 - 1 - p.Wp) * a_row_bytes + (long long)p.a_coff * 2 + src_chunk * 16;
+    const char* pb = p.Wt + (long long)(n0 + chan) * b_row_bytes + (long long)kx * p.K * 2 + src_chunk * 16;
+    gp[q] = slot_is_a[q] ? pa : pb;
+  }
+  const bool has_slot5 = wave + 40 < C::SG;
+  auto issue = [&](int q, int buf, long long offA, long long offB) {
+    const long long off = slot_is_a[q] ? offA : offB;
+    __builtin_amdgcn_global_load_lds((const UH_GLOBAL void*)(gp[q] + off),
+                                     (UH_LDS void*)(smem + buf * C::STAGE + (wave + 8 * q) * 1024), 16, 0, 0);
+  };
+  // row flags of this wave's 64 rows: 16 dwords of the row mask (lanes 16.. repeat them)
+  const long long mask_last_dword = (p.Mp - 1) >> 2;
+  auto issue_flags = [&](int tile) {
+    long long d = (((long long)tile * BM + wm * 64) >> 2) + l15;
+    if (d > mask_last_dword) d = mask_last_dword;
+    __builtin_amdgcn_global_load_lds((const UH_GLOBAL void*)(p.rowmask + 4 * d),
+                                     (UH_LDS void*)(smem + C::FLAG_OFF + wave * 256), 4, 0, 0);
   };
 
   // ---- fragment read offsets (bytes inside a stage) -----------------------------------------------------
@@ -322,133 +338,181 @@ __global__ __launch_bounds__(512, 2) void conv_band_kernel(GemmArgs p, int ntm, 
   }
   const int b_off = C::AG * 1024 + (wn * 64 + l15) * 64 + ((g ^ ((l15 >> 1) & 2)) << 4);
 
-  f32x4 acc[4][4];
+  // ---- epilogue constants: this lane's four channels ---------------------------------------------------------
+  const int ncol = wn * 64 + l15 * 4;             // first of the lane's 4 channels inside the N tile
+  float cb[4] = {0.f, 0.f, 0.f, 0.f}, csc[4] = {1.f, 1.f, 1.f, 1.f};
+  if (MODE == UH_EPI_AFFINE_RELU) {
+    const f32x4 a4 = *(const f32x4*)(p.scale + n0 + ncol), b4 = *(const f32x4*)(p.shift + n0 + ncol);
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) { csc[j] = a4[j]; cb[j] = b4[j]; }
+  } else if (p.bias) {
+    const f32x4 b4 = *(const f32x4*)(p.bias + n0 + ncol);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int niter = 3 * KC;
-  // prologue: two stages in flight
-  stage(0, 0, 0);
-  int ky_n = 0, kc_n = 1;                       // coordinates of the next stage to issue
-  if (kc_n == KC) { kc_n = 0; ++ky_n; }
-  if (niter > 1) {
-    stage(1, ky_n, kc_n);
-    if (++kc_n == KC) { kc_n = 0; ++ky_n; }
+    for (int j = 0; j < 4; ++j) cb[j] = b4[j];
   }
-  int buf = 0;
-  for (int it = 0; it < niter; ++it) {
-    // wait for this wave's loads of stage `it`, leaving the next stage's loads in flight
-    if (it + 1 < niter) {
-      if (my_groups == (C::SG + 7) / 8)
-        __builtin_amdgcn_s_waitcnt(0x0F70 | (((C::SG + 7) / 8) & 0xF) | ((((C::SG + 7) / 8) >> 4) << 14));
-      else
-        __builtin_amdgcn_s_waitcnt(0x0F70 | (((C::SG + 7) / 8 - 1) & 0xF) | ((((C::SG + 7) / 8 - 1) >> 4) << 14));
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();               // stage `it` complete for every wave; stage it-1 fully consumed
-    asm volatile("" ::: "memory");
-    if (it + 2 < niter) {
-      int nb = buf + 2;
-      if (nb >= 3) nb -= 3;
-      stage(nb, ky_n, kc_n);
-      if (++kc_n == KC) { kc_n = 0; ++ky_n; }
-    }
-    const char* S = smem + buf * C::STAGE;
+  // consume the loads here, so that the compiler's wait for them is not placed inside the tile loop
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
+  for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(cb[j]), "v"(csc[j]));
+  float* red = (float*)(smem + C::RED_OFF);
+  auto flush_stats = [&](int tile) {              // needs: every wave's red[] writes of `tile` are two barriers old
+    if (tid < 2 * BN) {
+      const int which = tid / BN, col = tid % BN;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < C::WM; ++w) v += red[(w * 2 + which) * BN + col];
+      p.stat_partial[((long long)tile * 2 + which) * p.N + n0 + col] = v;
+    }
+  };
+
+  // ---- main loop ---------------------------------------------------------------------------------------------
+  // The stages of all of this workgroup's tiles form one stream s = 0 .. my_tiles*3*KC - 1 (tile, ky, kc).
+  // One iteration consumes one stage in three phases, one per kx.  A phase is a load part (8 fragment reads
+  // of this kx + 2 staging slots of a later stage), a barrier, 16 MFMAs, a barrier.  Waves 4-7 (the second
+  // wave on each SIMD) run one barrier behind waves 0-3, so on every SIMD one wave is in its MFMA part while
+  // the other is in its load part.
+  //   stage s is staged by: slots 0,1 in phase 1 of iteration s-2, slots 2,3 in phase 2 of s-2, slots 4,5 in
+  //   phase 0 of s-1; it is retired by the vmcnt(2) in phase 2 of s-1 (only slots 0,1 of stage s+1 are
+  //   younger) and first read after the second barrier of that phase, which both halves reach after their
+  //   wait.  Its buffer was last read in phase 2 of s-3, whose reads each wave has waited for before the
+  //   barriers that precede phase 1 of s-2.
+  const int niter = 3 * KC;
+  const int total = my_tiles * niter;
+  long long offA, offB;
+  int ky_n = 0, kc_n = 0, tile_n = t_first;
+  auto stage_offsets = [&]() {
+    offA = ((long long)tile_n * BM + (long long)ky_n * p.Wp) * a_row_bytes + kc_n * 64;
+    offB = ((long long)ky_n * 3 * p.K + kc_n * 32) * 2;
+  };
+  auto advance = [&]() {
+    if (++kc_n == KC) {
+      kc_n = 0;
+      if (++ky_n == 3) { ky_n = 0; tile_n += wstep; }
+    }
+    stage_offsets();
+  };
+  stage_offsets();
+#pragma unroll
+  for (int q = 0; q < 5; ++q) issue(q, 0, offA, offB);
+  if (has_slot5) issue(5, 0, offA, offB);
+  advance();                                    // -> stage 1
+#pragma unroll
+  for (int q = 0; q < 4; ++q) issue(q, 1, offA, offB);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wave >= 4) __builtin_amdgcn_s_barrier();  // the stagger
+
+  int buf = 0, s = 0;
+  for (int tile = t_first; tile < t_end; tile += wstep) {
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int it = 0; it < niter; ++it, ++s) {
+      const char* S = smem + buf * C::STAGE;
+      const int buf1 = (buf == 2) ? 0 : buf + 1;
+      const int buf2 = (buf == 0) ? 2 : buf - 1;
       bf16x8 af[4], bfr[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(S + a_off[kx] + i * 1024);
+      for (int kx = 0; kx < 3; ++kx) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(S + b_off + kx * (BN * 64) + j * 1024);
+        for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(S + b_off + kx * (BN * 64) + j * 1024);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(S + a_off[kx] + i * 1024);
+        if (kx == 0) {
+          if (it == 0) issue_flags(tile);
+          if (s + 1 < total) {
+            issue(4, buf1, offA, offB);
+            if (has_slot5) issue(5, buf1, offA, offB);
+          }
+        } else if (kx == 1) {
+          if (MODE == UH_EPI_RAW_STATS && it == 0 && tile != t_first) flush_stats(tile - wstep);
+          if (s + 2 < total) {
+            advance();
+            issue(0, buf2, offA, offB);
+            issue(1, buf2, offA, offB);
+          }
+        } else {
+          if (s + 2 < total) {
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            issue(2, buf2, offA, offB);
+            issue(3, buf2, offA, offB);
+          } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+        }
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+      }
+      buf = buf1;
     }
-    if (++buf == 3) buf = 0;
-  }
 
-  // ---- epilogue (same contract as conv_gemm_kernel) ---------------------------------------------------------
-  __syncthreads();
-  float* flag = (float*)(smem + C::FLAG_OFF);
-  float* red = (float*)(smem + C::RED_OFF);
-  for (int i = tid; i < BM; i += 512) {
-    const long long m = m0 + i;
-    flag[i] = (m < p.Mp && p.rowmask[m]) ? 1.f : 0.f;
-  }
-  __syncthreads();
-  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int col = wn * 64 + j * 16 + l15;
-    const int n = n0 + col;
-    float bias = 0.f, sc = 1.f, sh = 0.f;
-    if (p.mode == UH_EPI_AFFINE_RELU) {
-      sc = p.scale[n];
-      sh = p.shift[n];
-    } else {
-      bias = p.bias ? p.bias[n] : 0.f;
-    }
+    // ---- epilogue of this tile, straight from the accumulators ---------------------------------------------
+    // lane (l15, g) holds rows wm*64 + i*16 + g*4 + e and channels ncol + j of the tile
+    const long long mrow0 = (long long)tile * BM + wm * 64 + g * 4;
+    char* orow = p.out + ((mrow0 * p.o_cstride) + p.o_coff + n0 + ncol) * 2;
+    const long long o_row_bytes = (long long)p.o_cstride * 2;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int rbase = wm * 64 + i * 16 + g * 4;
-      const f32x4 f = *(const f32x4*)(flag + rbase);
+      const uint32_t fw = *(const uint32_t*)(smem + C::FLAG_OFF + wave * 256 + (i * 4 + g) * 4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float v = acc[i][j][e];
-        if (p.mode == UH_EPI_AFFINE_RELU) {
-          v = fmaxf(v * sc + sh, 0.f);
-        } else {
-          v += bias;
+        const long long m = mrow0 + i * 16 + e;
+        const float f = (m < p.Mp) ? (float)((fw >> (8 * e)) & 0xffu) : 0.f;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float x = acc[i][j][e];
+          if (MODE == UH_EPI_AFFINE_RELU) x = fmaxf(x * csc[j] + cb[j], 0.f);
+          else x += cb[j];
+          x *= f;
+          if (MODE == UH_EPI_RAW_STATS) {
+            s1[j] += x;
+            s2[j] += x * x;
+          }
+          v[j] = x;
         }
-        v *= f[e];
-        if (p.mode == UH_EPI_RAW_STATS) {
-          s1[j] += v;
-          s2[j] += v * v;
-          *(_Float16*)(smem + (rbase + e) * C::PITCH + col * 2) = f2h(v);
+        uint2 o;
+        if (MODE == UH_EPI_RAW_STATS) {
+          o.x = pack2h(v[0], v[1]);
+          o.y = pack2h(v[2], v[3]);
         } else {
-          *(bf16*)(smem + (rbase + e) * C::PITCH + col * 2) = f2bf(v);
+          o.x = pack2(v[0], v[1]);
+          o.y = pack2(v[2], v[3]);
         }
+        *(uint2*)(orow + (i * 16 + e) * o_row_bytes) = o;
       }
     }
-  }
-  if (p.mode == UH_EPI_RAW_STATS) {
+    if (MODE == UH_EPI_RAW_STATS) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      s1[j] += __shfl_xor(s1[j], 16, 64);
-      s1[j] += __shfl_xor(s1[j], 32, 64);
-      s2[j] += __shfl_xor(s2[j], 16, 64);
-      s2[j] += __shfl_xor(s2[j], 32, 64);
+      for (int j = 0; j < 4; ++j) {
+        s1[j] += __shfl_xor(s1[j], 16, 64);
+        s1[j] += __shfl_xor(s1[j], 32, 64);
+        s2[j] += __shfl_xor(s2[j], 16, 64);
+        s2[j] += __shfl_xor(s2[j], 32, 64);
+      }
       if (g == 0) {
-        const int col = wn * 64 + j * 16 + l15;
-        red[(wm * 2 + 0) * BN + col] = s1[j];
-        red[(wm * 2 + 1) * BN + col] = s2[j];
+        *(f32x4*)(red + (wm * 2 + 0) * BN + ncol) = f32x4{s1[0], s1[1], s1[2], s1[3]};
+        *(f32x4*)(red + (wm * 2 + 1) * BN + ncol) = f32x4{s2[0], s2[1], s2[2], s2[3]};
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // raw barriers do not wait for LDS writes
     }
   }
-  __syncthreads();
-  if (p.mode == UH_EPI_RAW_STATS && tid < 2 * BN) {
-    const int which = tid / BN, col = tid % BN;
-    float v = 0.f;
-#pragma unroll
-    for (int w = 0; w < C::WM; ++w) v += red[(w * 2 + which) * BN + col];
-    p.stat_partial[((long long)tile * 2 + which) * p.N + n0 + col] = v;
-  }
-  constexpr int CPR = BN / 8;
-#pragma unroll
-  for (int q = tid; q < BM * CPR; q += 512) {
-    const int row = q / CPR, cc = q % CPR;
-    const long long m = m0 + row;
-    if (m < p.Mp) {
-      const U4 v = *(const U4*)(smem + row * C::PITCH + cc * 16);
-      *(U4*)(p.out + (m * p.o_cstride + p.o_coff + n0 + cc * 8) * 2) = v;
-    }
+  if (wave < 4) __builtin_amdgcn_s_barrier();   // match the second half's extra barrier
+  if (MODE == UH_EPI_RAW_STATS) {
+    __syncthreads();
+    flush_stats(t_first + (my_tiles - 1) * wstep);
   }
 }
 
@@ -457,13 +521,25 @@ static void launch_band(const GemmArgs& p, hipStream_t st) {
   using C = BandCfg<BM, BN>;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)conv_band_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)conv_band_kernel<BM, BN, UH_EPI_RAW_STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)conv_band_kernel<BM, BN, UH_EPI_AFFINE_RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)conv_band_kernel<BM, BN, UH_EPI_MASKED>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     attr = true;
   }
   const int ntm = (int)((p.Mp + BM - 1) / BM);
-  const int tpx = (ntm + 7) / 8;
-  dim3 grid(8 * tpx, p.N / BN);
-  hipLaunchKernelGGL((conv_band_kernel<BM, BN>), grid, dim3(512), C::LDS_BYTES, st, p, ntm, tpx);
+  const int ntn = p.N / BN;
+  const int tpx = (ntm + 7) / 8;                   // M tiles per XCD
+  // one workgroup per CU: 256 CUs shared by the N tiles, a multiple of 8 workgroups per N tile
+  int gx = (256 / ntn) & ~7;
+  if (gx < 8) gx = 8;
+  if (gx > 8 * tpx) gx = 8 * tpx;
+  dim3 grid(gx, ntn);
+  if (p.mode == UH_EPI_RAW_STATS)
+    hipLaunchKernelGGL((conv_band_kernel<BM, BN, UH_EPI_RAW_STATS>), grid, dim3(512), C::LDS_BYTES, st, p, ntm, tpx);
+  else if (p.mode == UH_EPI_AFFINE_RELU)
+    hipLaunchKernelGGL((conv_band_kernel<BM, BN, UH_EPI_AFFINE_RELU>), grid, dim3(512), C::LDS_BYTES, st, p, ntm, tpx);
+  else
+    hipLaunchKernelGGL((conv_band_kernel<BM, BN, UH_EPI_MASKED>), grid, dim3(512), C::LDS_BYTES, st, p, ntm, tpx);
 }
 
 static bool use_wide_m(int N) { return N % 128 != 0; }  // N = 64, 192, ...: tiles 64 wide
