@@ -7,8 +7,8 @@ gradient all-reduce + Adam) on N MI355X GPUs, one process per GPU.
         --master-port P bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line.  `value` = images/s over all ranks (weak scaling: 32 images per GPU),
-inputs resident in HBM before the timed region.  `roofline` prices the dominant kernel (the MFMA
-implicit-GEMM convolution: forward, input-gradient and transposed-conv launches) as algorithmic
+inputs resident in HBM before the timed region.  `roofline` prices the dominant kernel (conv_band_kernel,
+the MFMA implicit-GEMM 3x3 convolution, forward and input-gradient launches) as algorithmic
 FLOPs / event-timed duration against the dense bf16 MFMA peak; `cpu_baseline` is the fp32 CPU oracle
 (oracle/ref_cpu.py, validated against the reference) on a bounded sample on the host cores.
 """
@@ -108,8 +108,8 @@ def main():
         ms = dt / args.steps * 1e3
         value = world * args.batch * args.steps / dt
         ks = timer.summary()
-        g = ks["conv_gemm"]
-        achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12            # TFLOP/s over all conv_gemm launches
+        g = ks["conv_band"]
+        achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12            # TFLOP/s over all conv_band_kernel launches
         scale = (args.size / IMG) ** 2
         out = {
             "metric": "train imgs/sec, UNet 256^2 bf16 fwd+bwd, 1/2/4/8 MI355X; % MFMA peak",
@@ -121,7 +121,7 @@ def main():
                        "global_batch": world * args.batch, "parallelism": f"dp{world}",
                        "loss_last_step": round(loss.item(), 6)},
             "step_mfma_frac": round(value / world * FLOP_PER_IMG_FWD_BWD * scale / PEAK_BF16_DENSE, 4),
-            "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel (conv3x3 fwd + dgrad, convT fwd + dgrad)",
+            "roofline": {"bound": "mfma", "kernel": "conv_band_kernel (all 3x3 convolutions: 17 forward + 17 input-gradient launches per step)",
                          "achieved": round(achieved, 1), "peak": PEAK_BF16_DENSE / 1e12, "unit": "TFLOP/s",
                          "frac": round(achieved * 1e12 / PEAK_BF16_DENSE, 4), "traffic": None,
                          "launches_per_step": g["launches"] // args.steps,

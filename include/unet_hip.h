@@ -28,7 +28,8 @@ const char* uh_last_error(void);
 int uh_version(void);
 /* zero guard rows required on each side of a padded-linear buffer of image width W */
 int uh_guard_rows(int W);
-/* rowmask[m] = 1 for interior rows, 0 for pad rows; m in [0, Mp) */
+/* rowmask[m] = 1 for interior rows, 0 for pad rows; m in [0, Mp).  Kernels read the mask four rows at a time:
+ * the buffer must be 4-byte aligned and readable up to the next multiple of 4 bytes (contents there are ignored). */
 int uh_rowmask_build(int B, int H, int W, uint8_t* rowmask, uh_stream s);
 
 /* ---- weight packing -------------------------------------------------------------------

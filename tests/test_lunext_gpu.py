@@ -81,12 +81,21 @@ def test_lunext_golden_small(golden_dir):
     print(f"logits max err {err:.4g} (max |ref| {want.abs().max().item():.4g}); loss {loss.item():.6f} vs {float(fx['train_loss']):.6f}")
     assert err <= LOGIT_REL * want.abs().max().item()
     assert abs(loss.item() - float(fx["train_loss"])) <= LOSS_REL * float(fx["train_loss"])
-    # gradients: full tensors of the small parameters against the fixture, loosely (8 samples per channel at the
-    # bridge BatchNorm); the tight statement is the emulation yardstick on the same inputs, below
+    # gradients.  With B=2 at 32x32 the bridge BatchNorm sees 8 samples per channel and the gradients around it are
+    # ill-conditioned: the fp32 oracle with 16-bit storage roundings inserted reaches cosines of only 0.03-0.67
+    # against the fixture for downconv4 / conv5_1.  So absolute thresholds are asserted only away from the bridge,
+    # the fp32 oracle is pinned to the fixture, and the HIP path must be no further from the fixture than twice
+    # the emulation is (the yardstick).
     ref_grads = {k[5:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("grad/")}
-    wc, wn = check_grads(model, ref_grads, cos_min=0.85, norm_tol=0.40, min_numel=64)   # a 3-element cosine says little
-    print(f"grads vs fixture: worst cosine {wc:.5f}, worst norm error {wn:.4f}")
-    yardstick(three_way(2, 3, 32, 32, "cldice", seed=0, x=x.cpu(), m=m.cpu()), "golden inputs")
+    o = three_way(2, 3, 32, 32, "cldice", seed=0, x=x.cpu(), m=m.cpu())
+    for n, g in ref_grads.items():
+        got = o["ref"]["grads"][n]
+        if g.numel() >= 64 and not n.endswith("depthwise.bias"):
+            assert cosine(got, g) >= 0.999, f"oracle vs fixture {n}"
+    away = {n: g for n, g in ref_grads.items() if not n.startswith(("downconv4", "conv5_1"))}
+    wc, wn = check_grads(model, away, cos_min=0.85, norm_tol=0.40, min_numel=64)   # a 3-element cosine says little
+    print(f"grads vs fixture (away from the bridge): worst cosine {wc:.5f}, worst norm error {wn:.4f}")
+    yardstick(o, "golden inputs")
     model.eval()
     with torch.no_grad():
         ev = model(x).cpu()

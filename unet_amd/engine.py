@@ -59,7 +59,8 @@ class UNetRun:
         if self.timer is None:
             return call("uh_conv_gemm", *args)
         B, H, W, K, N, T = args[0], args[1], args[2], args[6], args[8], args[9]
-        with self.timer.launch("conv_gemm", 2.0 * B * H * W * K * N * T):
+        # T = 9 runs conv_band_kernel, T = 1 (transposed convs as GEMMs) conv_gemm_kernel
+        with self.timer.launch("conv_band" if T == 9 else "conv_gemm_t1", 2.0 * B * H * W * K * N * T):
             call("uh_conv_gemm", *args)
 
     def _wgrad(self, *args):
