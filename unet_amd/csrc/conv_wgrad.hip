@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs p) {
 static int wgrad_splits(long long Mp, int N, int K) {
   const long long stages = (Mp + 127) / 128;
   const long long tiles = (long long)(N / 64) * (K / 64);
-  long long want = (1024 + tiles - 1) / tiles;       // aim at ~1024 workgroups
+  long long want = (512 + tiles - 1) / tiles;        // aim at ~512 workgroups (two per CU): every split costs a slab
   if (want > stages) want = stages;
   if (want < 1) want = 1;
   if (want > 512) want = 512;
@@ -195,20 +195,93 @@ extern "C" int uh_conv_wgrad(int B, int H, int W, const void* dy, int dy_cstride
 }
 
 // grad[n*sn + t*st + k*sk] (+)= sum_s partial[s*split_stride + n*on + t*ot + k]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int S, long long split_stride, int N, int T,
-                                    int K, long long on, long long ot, long long sn, long long st, long long sk,
-                                    float* __restrict__ grad, int accumulate) {
+// A block owns 256/SL consecutive source elements; SL threads share each element and take every SL-th split
+// (many splits of a small tensor would otherwise be one long serial loop per thread).
+template <int SL>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int S, long long split_stride,
+                                                           int N, int T, int K, long long on, long long ot, long long sn,
+                                                           long long st, long long sk, float* __restrict__ grad,
+                                                           int accumulate) {
+  constexpr int EPB = 256 / SL;
+  __shared__ float red[SL][EPB];
   const long long total = (long long)N * T * K;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int k = (int)(i % K);
+  const int e = threadIdx.x % EPB, sl = threadIdx.x / EPB;
+  const long long i = (long long)blockIdx.x * EPB + e;
+  int k = 0, t = 0, n = 0;
+  float v = 0.f;
+  if (i < total) {
+    k = (int)(i % K);
     const long long r = i / K;
-    const int t = (int)(r % T);
-    const int n = (int)(r / T);
-    const long long src = n * on + t * ot + k;
-    float v = 0.f;
-    for (int s = 0; s < S; ++s) v += partial[s * split_stride + src];
+    t = (int)(r % T);
+    n = (int)(r / T);
+    const float* src = partial + n * on + t * ot + k;
+    for (int sp = sl; sp < S; sp += SL) v += src[sp * split_stride];
+  }
+  red[sl][e] = v;
+  __syncthreads();
+  if (sl == 0 && i < total) {
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < SL; ++j) sum += red[j][e];
     const long long dst = n * sn + t * st + k * sk;
-    grad[dst] = accumulate ? grad[dst] + v : v;
+    grad[dst] = accumulate ? grad[dst] + sum : sum;
+  }
+}
+
+// Transposed-conv weights, partial [tap][co][k] -> grad [k][co][tap] (T = 4): one block sums a
+// (64 k) x (4 co) x (4 taps) piece and writes 64-byte runs instead of single floats one row apart.
+__global__ __launch_bounds__(256) void wgrad_reduce_convt_kernel(const float* __restrict__ partial, int S,
+                                                                 long long split_stride, int Cout, int K,
+                                                                 float* __restrict__ grad, int accumulate) {
+  __shared__ float red[4][64][17];
+  const int k0 = blockIdx.x * 64, co0 = blockIdx.y * 4;
+  const int kk = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  float acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  for (int sp = sl; sp < S; sp += 4) {
+    const float* q = partial + sp * split_stride + k0 + kk;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[c * 4 + t] += q[((long long)t * Cout + co0 + c) * K];
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) red[sl][kk][j] = acc[j];
+  __syncthreads();
+  for (int o = threadIdx.x; o < 64 * 16; o += 256) {
+    const int r = o >> 4, j = o & 15;
+    const float v = (red[0][r][j] + red[1][r][j]) + (red[2][r][j] + red[3][r][j]);
+    float* dst = grad + ((long long)(k0 + r) * Cout + co0) * 4 + j;
+    *dst = accumulate ? *dst + v : v;
+  }
+}
+
+// The common case, partial [n][9][k] -> OIHW grad[n][k][9]: a direct write would scatter 4-byte stores 36 bytes
+// apart.  One block sums a (n, 64 k, 9 taps) piece -- four threads share each k and take every fourth split,
+// reading 256-byte runs -- and transposes it through LDS, so the 576 results leave as one contiguous run.
+__global__ __launch_bounds__(256) void wgrad_reduce_oihw9_kernel(const float* __restrict__ partial, int S,
+                                                                  long long split_stride, int K,
+                                                                  float* __restrict__ grad, int accumulate) {
+  __shared__ float red[4][9 * 64 + 8];
+  const int n = blockIdx.y, k0 = blockIdx.x * 64;
+  const int kk = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  float acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+  const float* base = partial + (long long)n * 9 * K + k0 + kk;
+  for (int sp = sl; sp < S; sp += 4) {
+    const float* q = base + sp * split_stride;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] += q[(long long)t * K];
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t) red[sl][kk * 9 + t] = acc[t];
+  __syncthreads();
+  float* dst = grad + ((long long)n * K + k0) * 9;
+  for (int j = threadIdx.x; j < 9 * 64; j += 256) {
+    const float v = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
+    dst[j] = accumulate ? dst[j] + v : v;
   }
 }
 
@@ -216,11 +289,25 @@ extern "C" int uh_wgrad_reduce_strided(const float* partial, int S, long long sp
                                        long long on, long long ot, long long sn, long long st, long long sk,
                                        float* grad, int accumulate, uh_stream s) {
   UH_REQUIRE(partial && grad && S > 0 && N > 0 && T > 0 && K > 0 && split_stride > 0, "wgrad_reduce: bad arguments");
+  if (T == 9 && K % 64 == 0 && on == 9LL * K && ot == K && sn == 9LL * K && st == 1 && sk == 9 && N <= 65535) {
+    hipLaunchKernelGGL(wgrad_reduce_oihw9_kernel, dim3(K / 64, N), dim3(256), 0, (hipStream_t)s, partial, S,
+                       split_stride, K, grad, accumulate);
+    return uh_check_launch("wgrad_reduce");
+  }
+  if (T == 4 && K % 64 == 0 && N % 4 == 0 && on == K && ot == (long long)N * K && sn == 4 && st == 1 &&
+      sk == 4LL * N && N / 4 <= 65535) {
+    hipLaunchKernelGGL(wgrad_reduce_convt_kernel, dim3(K / 64, N / 4), dim3(256), 0, (hipStream_t)s, partial, S,
+                       split_stride, N, K, grad, accumulate);
+    return uh_check_launch("wgrad_reduce");
+  }
   const long long total = (long long)N * T * K;
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, partial, S, split_stride, N, T, K,
-                     on, ot, sn, st, sk, grad, accumulate);
+  if (S >= 64 && total <= 65536) {
+    hipLaunchKernelGGL((wgrad_reduce_kernel<32>), dim3((unsigned)((total + 7) / 8)), dim3(256), 0, (hipStream_t)s, partial,
+                       S, split_stride, N, T, K, on, ot, sn, st, sk, grad, accumulate);
+  } else {
+    hipLaunchKernelGGL((wgrad_reduce_kernel<4>), dim3((unsigned)((total + 63) / 64)), dim3(256), 0, (hipStream_t)s, partial,
+                       S, split_stride, N, T, K, on, ot, sn, st, sk, grad, accumulate);
+  }
   return uh_check_launch("wgrad_reduce");
 }
 
