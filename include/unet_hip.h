@@ -63,6 +63,18 @@ int uh_conv_gemm(int B, int H, int W,
                  void* out, int o_cstride, int o_coff,
                  const float* bias, const float* scale, const float* shift,
                  float* stat_partial, const uint8_t* rowmask, uh_stream s);
+/* Same, with scratch memory that lets the T = 9 kernel cut its work evenly over the CUs even when the number of
+ * output tiles is not a multiple of the CU count (pieces of tiles are summed in a second launch).  Results do
+ * not depend on the cut.  workspace: 16-byte aligned, uh_conv_gemm_workspace() bytes; NULL or too small = whole
+ * tiles per workgroup, as uh_conv_gemm. */
+size_t uh_conv_gemm_workspace(int B, int H, int W, int K, int N, int T);
+int uh_conv_gemm_ws(int B, int H, int W,
+                    const void* a, int a_cstride, int a_coff, int K,
+                    const void* w_packed, int N, int T, int mode,
+                    void* out, int o_cstride, int o_coff,
+                    const float* bias, const float* scale, const float* shift,
+                    float* stat_partial, const uint8_t* rowmask,
+                    void* workspace, size_t workspace_bytes, uh_stream s);
 /* number of M tiles (= rows of stat_partial) uh_conv_gemm uses for this problem */
 int uh_conv_gemm_mtiles(int B, int H, int W, int N);
 

@@ -1,6 +1,6 @@
 """micro-benchmark of uh_conv_gemm / uh_conv_wgrad on UNet layer shapes (B=32, 256^2)"""
 import sys, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from unet_amd import _lib
 from unet_amd._lib import call, lib
 from unet_amd.layout import new_act, pool_for
@@ -9,9 +9,9 @@ S = lambda: torch.cuda.current_stream().cuda_stream
 shapes = {  # name: (B,H,W,Cin,Cout)
   'conv1_2': (32,256,256,64,64), 'conv2_2': (32,128,128,128,128), 'conv3_2': (32,64,64,256,256),
   'conv4_2': (32,32,32,512,512), 'conv5_2': (32,16,16,1024,1024), 'conv_up1_1': (32,32,32,1024,512),
-  'conv_up3_1': (32,128,128,256,128), 'conv_up4_1': (32,256,256,128,64),
+  'conv_up3_1': (32,128,128,256,128), 'conv_up4_1': (32,256,256,128,64), 'conv_up2_1': (32,64,64,512,256),
 }
-which = sys.argv[1].split(',') if len(sys.argv) > 1 else list(shapes)
+which = sys.argv[1].split(',') if len(sys.argv) > 1 and sys.argv[1] != 'all' else list(shapes)
 mode = sys.argv[2] if len(sys.argv) > 2 else 'fwd'
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 for name in which:
@@ -25,6 +25,10 @@ for name in which:
     bias = torch.zeros(Cout, device=DEV)
     if mode == 'fwd':
         f = lambda: call("uh_conv_gemm", B,H,W,a.ptr,a.cstride,0,Cin,w.data_ptr(),Cout,9,_lib.EPI_RAW_STATS,out.ptr,out.cstride,0,bias.data_ptr(),None,None,stat.data_ptr(),mask.data_ptr(),S())
+    elif mode == 'fwdws':
+        need = lib.uh_conv_gemm_workspace(B,H,W,Cin,Cout,9)
+        ws = torch.empty(need//4, device=DEV)
+        f = lambda: call("uh_conv_gemm_ws", B,H,W,a.ptr,a.cstride,0,Cin,w.data_ptr(),Cout,9,_lib.EPI_RAW_STATS,out.ptr,out.cstride,0,bias.data_ptr(),None,None,stat.data_ptr(),mask.data_ptr(),ws.data_ptr(),need,S())
     else:
         dy = new_act(B,H,W,Cout,DEV); dy.buf.normal_()
         Sp = lib.uh_conv_wgrad_splits(B,H,W,Cout,Cin,9)

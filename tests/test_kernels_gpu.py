@@ -93,6 +93,45 @@ def test_conv_gemm_raw_stats(B, H, W, Cin, Cout):
     close(s[1], (want * want).sum((0, 2, 3)), 2e-3, "sum y^2")
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 32, 32, 64, 128), (1, 16, 16, 128, 64), (2, 48, 48, 64, 256),
+                                            (1, 16, 16, 64, 64)])
+def test_conv_gemm_even_cuts(B, H, W, Cin, Cout):
+    """uh_conv_gemm_ws: workgroups that own pieces of tiles + the fix-up launch give the whole-tile result."""
+    g = torch.Generator().manual_seed(B * 77 + H + Cin)
+    x = bf(torch.randn(B, Cin, H, W, generator=g))
+    w = bf(torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5))
+    b = torch.randn(Cout, generator=g)
+    a = act_from(x)
+    wd, bd = w.to(DEV), b.to(DEV)
+    pk = pack_conv(wd)
+    parts = lib.uh_conv_gemm_mtiles(B, H, W, Cout)
+    need = lib.uh_conv_gemm_workspace(B, H, W, Cin, Cout, 9)
+    assert need > 0 and lib.uh_conv_gemm_workspace(B, H, W, Cin, Cout, 1) == 0
+    ws = torch.full((need // 4,), float("nan"), device=DEV)        # stale contents must not matter
+    outs, stats = [], []
+    for use_ws in (False, True):
+        out = new_act(B, H, W, Cout, DEV)
+        stat = torch.zeros(parts, 2, Cout, device=DEV)
+        call("uh_conv_gemm_ws", B, H, W, a.ptr, a.cstride, a.coff, Cin, pk.data_ptr(), Cout, 9, _lib.EPI_RAW_STATS,
+             out.ptr, out.cstride, out.coff, bd.data_ptr(), None, None, stat.data_ptr(), rowmask(B, H, W).data_ptr(),
+             ws.data_ptr() if use_ws else None, need if use_ws else 0, S())
+        torch.cuda.synchronize()
+        pads_are_zero(out)
+        outs.append(out.to_nchw(half=True))
+        stats.append(stat.cpu())
+    want = F.conv2d(x, w, b, padding=1)
+    close(outs[1], want, 2e-3, "conv output, even cuts")
+    close(outs[1], outs[0], 1e-3, "even cuts vs whole tiles")
+    close(stats[1], stats[0], 1e-4, "BatchNorm partial sums, even cuts vs whole tiles")
+    # input gradient mode through the same path
+    out = new_act(B, H, W, Cout, DEV)
+    call("uh_conv_gemm_ws", B, H, W, a.ptr, a.cstride, a.coff, Cin, pk.data_ptr(), Cout, 9, _lib.EPI_MASKED,
+         out.ptr, out.cstride, out.coff, None, None, None, None, rowmask(B, H, W).data_ptr(), ws.data_ptr(), need, S())
+    torch.cuda.synchronize()
+    close(out.to_nchw(), F.conv2d(x, w, None, padding=1), 1e-2, "masked mode, even cuts")
+    pads_are_zero(out)
+
+
 def test_conv_gemm_affine_relu_and_views():
     """eval-mode epilogue, reading from and writing into channel windows of wider buffers."""
     B, H, W, Cin, Cout = 2, 8, 8, 64, 128

@@ -95,7 +95,7 @@ def test_lunext_golden_small(golden_dir):
     away = {n: g for n, g in ref_grads.items() if not n.startswith(("downconv4", "conv5_1"))}
     wc, wn = check_grads(model, away, cos_min=0.85, norm_tol=0.40, min_numel=64)   # a 3-element cosine says little
     print(f"grads vs fixture (away from the bridge): worst cosine {wc:.5f}, worst norm error {wn:.4f}")
-    yardstick(o, "golden inputs", min_numel=64)
+    yardstick(o, "golden inputs", min_numel=64, skip=("downconv4", "conv5_1"))
     model.eval()
     with torch.no_grad():
         ev = model(x).cpu()
@@ -130,9 +130,10 @@ def three_way(B, C, H, W, loss, seed=4, x=None, m=None):
     return outs
 
 
-def yardstick(o, what, min_numel=1):
+def yardstick(o, what, min_numel=1, skip=()):
     """HIP may be at most twice as far from the fp32 oracle as the 16-bit-storage emulation of the oracle is.
-    (min_numel: skip tensors with fewer elements -- one noise sample of a 3-element gradient is no yardstick.)"""
+    (min_numel / skip: tensors left out -- one noise sample of a 3-element gradient is no yardstick, and neither
+    is a gradient that the emulation itself gets uncorrelated with the oracle.)"""
     ref, emu, hip = o["ref"], o["emu"], o["hip"]
     scale = ref["logits"].abs().max().item()
     err_hip = (hip["logits"] - ref["logits"]).abs().max().item()
@@ -150,7 +151,7 @@ def yardstick(o, what, min_numel=1):
         if n.endswith("depthwise.bias"):
             assert g_hip.abs().max().item() <= 1e-3 * total, n     # analytically zero under train-mode BN
             continue
-        if g_ref.numel() < min_numel:
+        if g_ref.numel() < min_numel or n.startswith(skip):
             continue
         d_hip, d_emu = 1.0 - cosine(g_hip, g_ref), 1.0 - cosine(g_emu, g_ref)
         n_hip = abs(g_hip.norm().item() / g_ref.norm().item() - 1.0)

@@ -52,16 +52,23 @@ class UNetRun:
         self.masks = [self.pool.rowmask(*g) for g in self.geo]
         self.grad_alloc = self.on_ready = None
         self.timer = None          # optional KernelTimer (bench): times selected kernel launches with events
+        self._ws, self._ws_bytes = None, 0
 
     # ------------------------------------------------------------------ helpers
     def _gemm(self, *args):
         """uh_conv_gemm; with a KernelTimer attached, bracketed by events on the launching stream."""
-        if self.timer is None:
-            return call("uh_conv_gemm", *args)
         B, H, W, K, N, T = args[0], args[1], args[2], args[6], args[8], args[9]
+        # one scratch buffer per run serves every 3x3 launch (they are ordered on the stream)
+        need = _lib.lib.uh_conv_gemm_workspace(B, H, W, K, N, T)
+        if need > self._ws_bytes:
+            self._ws = self.lease.f32((need + 3) // 4)
+            self._ws_bytes = need
+        args = args[:-1] + (self._ws.data_ptr() if need else None, self._ws_bytes if need else 0, args[-1])
+        if self.timer is None:
+            return call("uh_conv_gemm_ws", *args)
         # T = 9 runs conv_band_kernel, T = 1 (transposed convs as GEMMs) conv_gemm_kernel
         with self.timer.launch("conv_band" if T == 9 else "conv_gemm_t1", 2.0 * B * H * W * K * N * T):
-            call("uh_conv_gemm", *args)
+            call("uh_conv_gemm_ws", *args)
 
     def _wgrad(self, *args):
         if self.timer is None:
