@@ -34,7 +34,7 @@ def test_host_only_entry_points():
     lib = _lib.lib
     assert lib.uh_version() >= 1
     assert lib.uh_guard_rows(256) >= 256 + 2 + 512 + 16
-    assert lib.uh_conv_gemm_mtiles(32, 256, 256, 64) == (32 * 257 * 257 + 255) // 256
+    assert lib.uh_conv_gemm_mtiles(32, 256, 256, 64) == (32 * 257 * 257 + 511) // 512
     assert lib.uh_conv_gemm_mtiles(32, 256, 256, 128) == (32 * 257 * 257 + 255) // 256
     s = lib.uh_conv_wgrad_splits(32, 256, 256, 64, 64, 9)
     assert 1 <= s <= 512 and lib.uh_conv_wgrad_workspace(32, 256, 256, 64, 64, 9) == s * 64 * 9 * 64 * 4

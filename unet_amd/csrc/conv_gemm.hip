@@ -12,8 +12,24 @@
 // along the channel axis, and fuses: bias, BatchNorm batch statistics (per-tile partial sums),
 // folded BatchNorm+ReLU (inference), pad-row zeroing, and the pixel-shuffle scatter of a
 // stride-2 transposed convolution.
-#include "conv_args.h"
+#include "common.h"
 
+struct GemmArgs {
+  const char* A;
+  const char* Wt;
+  char* out;
+  const float* bias;
+  const float* scale;
+  const float* shift;
+  float* stat_partial;
+  const uint8_t* rowmask;
+  long long Mp;
+  int a_cstride, a_coff, K, N, T, KC;  // KC = K/64
+  int Wp;                              // row pitch of the A geometry (W+1)
+  int o_cstride, o_coff, mode;
+  int H, W;                            // A geometry (for the transposed-conv scatter)
+  int Cout;                            // transposed conv: N = 4*Cout
+};
 
 template <int BM, int BN>
 struct Cfg {
@@ -217,17 +233,456 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmArgs p) {
   }
 }
 
+// ===================================================================================================
+// 3x3 "band" kernel: the workhorse for T = 9.
+//
+// Measured on MI355X the tile kernel above is bound by the global->LDS path (staging alone takes 80-97 %
+// of its time), and its per-tile prologue and LDS-transposing epilogue are exposed.  (Also measured, on this
+// kernel: with all loads removed its barrier/MFMA skeleton is only ~1.3x faster, with the MFMAs removed the
+// loads alone take ~70 % of the full time; 128-byte row pieces, 128x64 wave tiles with 512-row tiles, and
+// filter-row-innermost iteration order each left the speed unchanged within 5 %.)  This kernel
+//   * stages fewer bytes per FLOP: the three taps of one filter row (kx = 0,1,2) read the SAME activation
+//     rows shifted by one, so one staged band of BM+2 rows serves three taps; tiles are 256x128 or 512x64
+//     with eight waves of 64x64;
+//   * consumes K 32 channels at a time through a three-stage LDS ring (A band + 3 weight taps per stage)
+//     behind counted s_waitcnt and raw s_barriers, with the two waves of every SIMD alternating between a
+//     load part and an MFMA part (see the main loop);
+//   * is persistent: one workgroup per CU walks a list of M tiles and the ring runs on across tile
+//     boundaries, so the next tile's first stages are already in LDS while this tile's results are stored;
+//   * stores straight from the accumulators: the weight rows are staged in permuted order (LDS row
+//     16*j + c holds output channel 4*c + j of the wave's 64), so the four accumulator tiles a lane holds
+//     for one activation row are four ADJACENT channels -> one 8-byte store per row, 16 lanes = one
+//     128-byte line.  BatchNorm partial sums are reduced across waves through a small LDS array that is
+//     flushed to global memory a few barriers later, from inside the next tile.
+// LDS rows are 64 B; chunk c of row r sits at position c ^ ((r>>1)&2), which keeps ds_read_b128 fragment
+// reads conflict-free for every row shift (checked exhaustively against the gfx950 lane groups).
+// Workgroups b, b+8, ... share an XCD; each XCD walks one contiguous range of M tiles so that the band
+// rows neighbouring tiles share, and the A rows that all N tiles share, hit in its L2.
+template <int BM, int BN>
+struct BandCfg {
+  static constexpr int WN = BN / 64;
+  static constexpr int WM = 8 / WN;
+  static_assert(BM == WM * 64, "each of the eight waves owns 64 rows");
+  static constexpr int AG = BM / 16 + 1;          // 1 KiB groups (16 rows x 64 B) of the A band: BM+16 >= BM+2 rows
+  static constexpr int BGT = BN / 16;             // groups per weight tap
+  static constexpr int SG = AG + 3 * BGT;         // groups per stage
+  static constexpr int STAGE = SG * 1024;
+  static constexpr int NSTAGE = 3;
+  static constexpr int FLAG_OFF = NSTAGE * STAGE;             // 8 waves x 64 dwords of row flags
+  static constexpr int RED_OFF = FLAG_OFF + 8 * 256;          // float[WM][2][BN]
+  static constexpr int LDS_BYTES = RED_OFF + WM * 2 * BN * 4;
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+// How the work of one launch is cut.  A "unit" is one BM x BN output tile (unit u: M tile u / ntn, N tile
+// u % ntn) and takes niter = 3*K/32 iterations; the launch is the sequence of all (unit, iteration) pairs and
+// workgroup position p takes the contiguous piece [band_start(p), band_start(p+1)).  With `aligned` the cuts
+// fall on unit boundaries (whole tiles per workgroup, uneven when units % G != 0).  Otherwise the cuts are
+// even in iterations: a piece that covers only part of a unit leaves its accumulators in `ws`
+// (slot 2p: the piece starts inside the unit, slot 2p+1: it ends inside), and conv_band_fixup_kernel sums
+// the pieces of every cut unit in position order and runs the epilogue -- a second launch instead of
+// workgroups waiting for each other.
+struct BandSched {
+  int ntm, ntn, niter, G, aligned;
+  float* ws;
+};
+
+__device__ __forceinline__ long long band_start(const BandSched& sc, int pos) {
+  const long long units = (long long)sc.ntm * sc.ntn;
+  return sc.aligned ? ((long long)pos * units / sc.G) * sc.niter : ((long long)pos * units * sc.niter) / sc.G;
+}
+
+// Epilogue of one unit, straight from the accumulators: lane (l15, g) of wave (wm, wn) holds rows
+// wm*64 + i*16 + g*4 + e and the 4 adjacent channels wn*64 + l15*4 + j of the tile; fw[i] = the four row
+// flags of rows i*16 + g*4 .. +3.  RAW_STATS leaves the wave's channel sums in red[wm][2][BN].
+template <int BM, int BN, int MODE>
+__device__ __forceinline__ void band_epilogue(const GemmArgs& p, const f32x4 (&acc)[4][4], int mt, int nt,
+                                              const uint32_t (&fw)[4], int wm, int wn, int l15, int g, float* red) {
+  const int ncol = wn * 64 + l15 * 4;
+  const int n0 = nt * BN;
+  float cb[4] = {0.f, 0.f, 0.f, 0.f}, csc[4] = {1.f, 1.f, 1.f, 1.f};
+  if (MODE == UH_EPI_AFFINE_RELU) {
+    const f32x4 a4 = *(const f32x4*)(p.scale + n0 + ncol), b4 = *(const f32x4*)(p.shift + n0 + ncol);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { csc[j] = a4[j]; cb[j] = b4[j]; }
+  } else if (p.bias) {
+    const f32x4 b4 = *(const f32x4*)(p.bias + n0 + ncol);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cb[j] = b4[j];
+  }
+  const long long mrow0 = (long long)mt * BM + wm * 64 + g * 4;
+  char* orow = p.out + ((mrow0 * p.o_cstride) + p.o_coff + n0 + ncol) * 2;
+  const long long o_row_bytes = (long long)p.o_cstride * 2;
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const long long m = mrow0 + i * 16 + e;
+      const float f = (m < p.Mp) ? (float)((fw[i] >> (8 * e)) & 0xffu) : 0.f;
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float x = acc[i][j][e];
+        if (MODE == UH_EPI_AFFINE_RELU) x = fmaxf(x * csc[j] + cb[j], 0.f);
+        else x += cb[j];
+        x *= f;
+        if (MODE == UH_EPI_RAW_STATS) {
+          s1[j] += x;
+          s2[j] += x * x;
+        }
+        v[j] = x;
+      }
+      uint2 o;
+      if (MODE == UH_EPI_RAW_STATS) {
+        o.x = pack2h(v[0], v[1]);
+        o.y = pack2h(v[2], v[3]);
+      } else {
+        o.x = pack2(v[0], v[1]);
+        o.y = pack2(v[2], v[3]);
+      }
+      *(uint2*)(orow + (i * 16 + e) * o_row_bytes) = o;
+    }
+  }
+  if (MODE == UH_EPI_RAW_STATS) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      s1[j] += __shfl_xor(s1[j], 16, 64);
+      s1[j] += __shfl_xor(s1[j], 32, 64);
+      s2[j] += __shfl_xor(s2[j], 16, 64);
+      s2[j] += __shfl_xor(s2[j], 32, 64);
+    }
+    if (g == 0) {
+      *(f32x4*)(red + (wm * 2 + 0) * BN + ncol) = f32x4{s1[0], s1[1], s1[2], s1[3]};
+      *(f32x4*)(red + (wm * 2 + 1) * BN + ncol) = f32x4{s2[0], s2[1], s2[2], s2[3]};
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // raw barriers do not wait for LDS writes
+  }
+}
+
+// red[WM][2][BN] -> stat_partial[mt][2][N]; every wave's red[] writes must be two barriers old
+template <int BM, int BN>
+__device__ __forceinline__ void band_flush_stats(const GemmArgs& p, const float* red, int mt, int nt, int tid) {
+  if (tid < 2 * BN) {
+    const int which = tid / BN, col = tid % BN;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < BandCfg<BM, BN>::WM; ++w) v += red[(w * 2 + which) * BN + col];
+    p.stat_partial[((long long)mt * 2 + which) * p.N + nt * BN + col] = v;
+  }
+}
+
+template <int BM, int BN, int MODE>
+__global__ __launch_bounds__(512) void conv_band_kernel(GemmArgs p, BandSched sc) {
+  using C = BandCfg<BM, BN>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // workgroups b, b+8, ... share an XCD: give each XCD one contiguous run of positions
+  const int pos = (blockIdx.x & 7) * (sc.G >> 3) + (blockIdx.x >> 3);
+  const long long i0 = band_start(sc, pos), i1 = band_start(sc, pos + 1);
+  if (i0 >= i1) return;
+  const int total = (int)(i1 - i0);
+  const int niter = sc.niter, ntn = sc.ntn;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / C::WN, wn = wave % C::WN;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int KC = p.K / 32;
+
+  // ---- staging: one wave instruction = 16 rows x 64 B; lane -> (row lane/4, position lane%4) ----------
+  // A stage is SG groups; wave w stages groups w, w+8, ... ("slots" q = 0..5; only slot 5 can be absent).
+  // Slot pointers are fixed up front; a stage adds one of two wave-uniform offsets (activation / weight).
+  constexpr int NQ = 6;
+  static_assert((C::SG + 7) / 8 == NQ, "six staging slots per wave");
+  const int srow = lane >> 2;
+  const int src_chunk = (lane & 3) ^ ((srow >> 1) & 2);
+  const long long a_row_bytes = (long long)p.a_cstride * 2;
+  const long long b_row_bytes = 9LL * p.K * 2;
+  const char* gp[NQ];
+  bool slot_is_a[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int gi = wave + 8 * q;
+    slot_is_a[q] = gi < C::AG;
+    const int j = gi - C::AG;
+    const int kx = j / C::BGT, nb = j % C::BGT;
+    // weight group nb = LDS rows 16*nb .. 16*nb+15 of the tap = accumulator tile (nb%4) of wave column nb/4
+    const int chan = (nb >> 2) * 64 + srow * 4 + (nb & 3);
+    const char* pa = p.A + (srow + (long long)gi * 16 - 1 - p.Wp) * a_row_bytes + (long long)p.a_coff * 2 + src_chunk * 16;
+    const char* pb = p.Wt + (long long)chan * b_row_bytes + (long long)kx * p.K * 2 + src_chunk * 16;
+    gp[q] = slot_is_a[q] ? pa : pb;
+  }
+  const bool has_slot5 = wave + 40 < C::SG;
+  auto issue = [&](int q, int buf, long long offA, long long offB) {
+    const long long off = slot_is_a[q] ? offA : offB;
+    __builtin_amdgcn_global_load_lds((const UH_GLOBAL void*)(gp[q] + off),
+                                     (UH_LDS void*)(smem + buf * C::STAGE + (wave + 8 * q) * 1024), 16, 0, 0);
+  };
+  // row flags of this wave's 64 rows: 16 dwords of the row mask (lanes 16.. repeat them)
+  const long long mask_last_dword = (p.Mp - 1) >> 2;
+  auto issue_flags = [&](int mt) {
+    long long d = (((long long)mt * BM + wm * 64) >> 2) + l15;
+    if (d > mask_last_dword) d = mask_last_dword;
+    __builtin_amdgcn_global_load_lds((const UH_GLOBAL void*)(p.rowmask + 4 * d),
+                                     (UH_LDS void*)(smem + C::FLAG_OFF + wave * 256), 4, 0, 0);
+  };
+
+  // ---- fragment read offsets (bytes inside a stage) -----------------------------------------------------
+  int a_off[3];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx) {
+    const int r = l15 + kx;
+    a_off[kx] = (wm * 64 + r) * 64 + ((g ^ ((r >> 1) & 2)) << 4);
+  }
+  const int b_off = C::AG * 1024 + (wn * 64 + l15) * 64 + ((g ^ ((l15 >> 1) & 2)) << 4);
+  float* red = (float*)(smem + C::RED_OFF);
+
+  // ---- main loop ---------------------------------------------------------------------------------------------
+  // The (unit, iteration) pairs of this workgroup form one stream of stages s = 0 .. total-1; a stage is one
+  // filter row ky and 32 channels.  One iteration consumes one stage in three phases, one per kx.  A phase is
+  // a load part (8 fragment reads of this kx + 2 staging slots of a later stage), a barrier, 16 MFMAs, a
+  // barrier.  Waves 4-7 (the second wave on each SIMD) run one barrier behind waves 0-3, so on every SIMD one
+  // wave is in its MFMA part while the other is in its load part.
+  //   stage s is staged by: slots 0,1 in phase 1 of iteration s-2, slots 2,3 in phase 2 of s-2, slots 4,5 in
+  //   phase 0 of s-1; it is retired by the vmcnt(2) in phase 2 of s-1 (only slots 0,1 of stage s+1 are
+  //   younger) and first read after the second barrier of that phase, which both halves reach after their
+  //   wait.  Its buffer was last read in phase 2 of s-3, whose reads each wave has waited for before the
+  //   barriers that precede phase 1 of s-2.
+  long long offA, offB;
+  int u_n = (int)(i0 / niter);
+  int mt_n = u_n / ntn, nt_n = u_n % ntn;
+  int ky_n, kc_n;
+  {
+    const int it0 = (int)(i0 - (long long)u_n * niter);
+    ky_n = it0 / KC;
+    kc_n = it0 % KC;
+  }
+  auto stage_offsets = [&]() {
+    offA = ((long long)mt_n * BM + (long long)ky_n * p.Wp) * a_row_bytes + kc_n * 64;
+    offB = (long long)nt_n * BN * b_row_bytes + ((long long)ky_n * 3 * p.K + kc_n * 32) * 2;
+  };
+  auto advance = [&]() {
+    if (++kc_n == KC) {
+      kc_n = 0;
+      if (++ky_n == 3) {
+        ky_n = 0;
+        if (++nt_n == ntn) { nt_n = 0; ++mt_n; }
+      }
+    }
+    stage_offsets();
+  };
+  stage_offsets();
+#pragma unroll
+  for (int q = 0; q < 5; ++q) issue(q, 0, offA, offB);
+  if (has_slot5) issue(5, 0, offA, offB);
+  if (total > 1) {
+    advance();                                  // -> stage 1
+#pragma unroll
+    for (int q = 0; q < 4; ++q) issue(q, 1, offA, offB);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  if (wave >= 4) __builtin_amdgcn_s_barrier();  // the stagger
+
+  int buf = 0, s = 0;
+  int pend_mt = -1, pend_nt = 0;                // unit whose BatchNorm sums still sit in red[]
+  long long i = i0;
+  bf16x8 af[4], bfr[4];
+  while (i < i1) {
+    const int u = (int)(i / niter);
+    const int it_a = (int)(i - (long long)u * niter);
+    const int cnt = min(niter - it_a, (int)(i1 - i));
+    const bool full = (it_a == 0 && cnt == niter);
+    const int mt = u / ntn, nt = u - mt * ntn;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[ii][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int c = 0; c < cnt; ++c, ++s) {
+      const char* S = smem + buf * C::STAGE;
+      const int buf1 = (buf == 2) ? 0 : buf + 1;
+      const int buf2 = (buf == 0) ? 2 : buf - 1;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(S + b_off + kx * (BN * 64) + j * 1024);
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) af[ii] = *(const bf16x8*)(S + a_off[kx] + ii * 1024);
+        if (kx == 0) {
+          if (c == 0 && full) issue_flags(mt);
+          if (s + 1 < total) {
+            issue(4, buf1, offA, offB);
+            if (has_slot5) issue(5, buf1, offA, offB);
+          }
+        } else if (kx == 1) {
+          if (MODE == UH_EPI_RAW_STATS && c == 0 && pend_mt >= 0) {
+            band_flush_stats<BM, BN>(p, red, pend_mt, pend_nt, tid);
+            pend_mt = -1;
+          }
+          if (s + 2 < total) {
+            advance();
+            issue(0, buf2, offA, offB);
+            issue(1, buf2, offA, offB);
+          }
+        } else {
+          if (s + 2 < total) {
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            issue(2, buf2, offA, offB);
+            issue(3, buf2, offA, offB);
+          } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+        }
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ii], bfr[j], acc[ii][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+      }
+      buf = buf1;
+    }
+    i += cnt;
+
+    if (full) {
+      uint32_t fw[4];
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii) fw[ii] = *(const uint32_t*)(smem + C::FLAG_OFF + wave * 256 + (ii * 4 + g) * 4);
+      band_epilogue<BM, BN, MODE>(p, acc, mt, nt, fw, wm, wn, l15, g, red);
+      if (MODE == UH_EPI_RAW_STATS) { pend_mt = mt; pend_nt = nt; }
+    } else {
+      // a piece of a unit: park the accumulators for conv_band_fixup_kernel
+      f32x4* slot = (f32x4*)sc.ws + ((long long)(2 * pos + (it_a > 0 ? 0 : 1)) * 16) * 512 + tid;
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) slot[(ii * 4 + j) * 512] = acc[ii][j];
+    }
+  }
+  if (wave < 4) __builtin_amdgcn_s_barrier();   // match the second half's extra barrier
+  if (MODE == UH_EPI_RAW_STATS && pend_mt >= 0) {
+    __syncthreads();
+    band_flush_stats<BM, BN>(p, red, pend_mt, pend_nt, tid);
+  }
+}
+
+// One workgroup per cut: boundary k (between positions k-1 and k) that falls inside a unit and is the first
+// such boundary of that unit sums the unit's pieces in position order and finishes the unit.
+template <int BM, int BN, int MODE>
+__global__ __launch_bounds__(512) void conv_band_fixup_kernel(GemmArgs p, BandSched sc) {
+  using C = BandCfg<BM, BN>;
+  __shared__ __attribute__((aligned(16))) float red[C::WM * 2 * BN];
+  const int k = blockIdx.x + 1;
+  const long long sk = band_start(sc, k);
+  const int niter = sc.niter;
+  if (sk % niter == 0) return;
+  const long long u = sk / niter, ub = u * niter, ue = ub + niter;
+  if (k >= 2 && band_start(sc, k - 1) > ub) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / C::WN, wn = wave % C::WN;
+  const int l15 = lane & 15, g = lane >> 4;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[ii][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int pp = k - 1; pp < sc.G; ++pp) {
+    const long long ps = band_start(sc, pp), pe = band_start(sc, pp + 1);
+    if (ps >= ue) break;
+    if (pe <= ps || pe <= ub) continue;
+    const int inside = (ps > ub) ? 0 : 1;        // slot 2pp: piece starts inside the unit; 2pp+1: it ends inside
+    const f32x4* slot = (const f32x4*)sc.ws + ((long long)(2 * pp + inside) * 16) * 512 + tid;
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[ii][j] += slot[(ii * 4 + j) * 512];
+  }
+  const int mt = (int)(u / sc.ntn), nt = (int)(u % sc.ntn);
+  uint32_t fw[4];
+  const long long mask_last_dword = (p.Mp - 1) >> 2;
+#pragma unroll
+  for (int ii = 0; ii < 4; ++ii) {
+    long long d = (((long long)mt * BM + wm * 64) >> 2) + ii * 4 + g;
+    if (d > mask_last_dword) d = mask_last_dword;
+    fw[ii] = *(const uint32_t*)(p.rowmask + 4 * d);
+  }
+  band_epilogue<BM, BN, MODE>(p, acc, mt, nt, fw, wm, wn, l15, g, red);
+  if (MODE == UH_EPI_RAW_STATS) {
+    __syncthreads();
+    band_flush_stats<BM, BN>(p, red, mt, nt, tid);
+  }
+}
+
+static int band_workgroups(long long units, int niter) {
+  const long long total = units * niter;
+  long long g = (total / 4) & ~7LL;               // at least ~4 iterations per workgroup
+  if (g > 256) g = 256;                           // one workgroup per CU
+  if (g < 8) g = 8;
+  return (int)g;
+}
+
+template <int BM, int BN>
+static size_t band_workspace_bytes(long long Mp, int N, int K) {
+  const long long units = ((Mp + BM - 1) / BM) * (N / BN);
+  return (size_t)2 * band_workgroups(units, 3 * (K / 32)) * BM * BN * sizeof(float);
+}
+
+template <int BM, int BN, int MODE>
+static void launch_band_mode(const GemmArgs& p, const BandSched& sc, hipStream_t st) {
+  using C = BandCfg<BM, BN>;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)conv_band_kernel<BM, BN, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    attr = true;
+  }
+  hipLaunchKernelGGL((conv_band_kernel<BM, BN, MODE>), dim3(sc.G), dim3(512), C::LDS_BYTES, st, p, sc);
+  if (!sc.aligned)
+    hipLaunchKernelGGL((conv_band_fixup_kernel<BM, BN, MODE>), dim3(sc.G - 1), dim3(512), 0, st, p, sc);
+}
+
+template <int BM, int BN>
+static void launch_band(const GemmArgs& p, void* ws, size_t ws_bytes, hipStream_t st) {
+  BandSched sc;
+  sc.ntm = (int)((p.Mp + BM - 1) / BM);
+  sc.ntn = p.N / BN;
+  sc.niter = 3 * (p.K / 32);
+  const long long units = (long long)sc.ntm * sc.ntn;
+  sc.G = band_workgroups(units, sc.niter);
+  sc.ws = (float*)ws;
+  // even cuts need the workspace and cost a second launch plus ~2 x 128 KB of traffic per workgroup, and the
+  // workgroups of a thinly populated last round run faster than those of a full one: measured, even cuts win
+  // from about a third of the CU-time idle (137x4 and 37x8 tiles on 256 CUs), not at a fifth (529x2 tiles)
+  const long long rounds = (units + sc.G - 1) / sc.G;
+  const bool wasteful = rounds * sc.G * 100 > units * 125;
+  sc.aligned = (ws == nullptr || ws_bytes < band_workspace_bytes<BM, BN>(p.Mp, p.N, p.K) || !wasteful) ? 1 : 0;
+  if (p.mode == UH_EPI_RAW_STATS) launch_band_mode<BM, BN, UH_EPI_RAW_STATS>(p, sc, st);
+  else if (p.mode == UH_EPI_AFFINE_RELU) launch_band_mode<BM, BN, UH_EPI_AFFINE_RELU>(p, sc, st);
+  else launch_band_mode<BM, BN, UH_EPI_MASKED>(p, sc, st);
+}
+
 static bool use_wide_m(int N) { return N % 128 != 0; }  // N = 64, 192, ...: tiles 64 wide
 
 // M tiles of the T = 9 path (rows of stat_partial in RAW_STATS mode)
 extern "C" int uh_conv_gemm_mtiles(int B, int H, int W, int N) {
-  (void)N;
-  return (int)((uh_mp(B, H, W) + UH_BAND_BM - 1) / UH_BAND_BM);
+  const long long Mp = uh_mp(B, H, W);
+  const int bm = use_wide_m(N) ? 512 : 256;
+  return (int)((Mp + bm - 1) / bm);
 }
 
 extern "C" size_t uh_conv_gemm_workspace(int B, int H, int W, int K, int N, int T) {
-  if (T != 9 || B <= 0 || H <= 0 || W <= 0 || K < 64 || N < 64) return 0;
-  return uh_band_workspace_bytes(uh_mp(B, H, W), N, K);
+  if (T != 9 || B <= 0 || H <= 0 || W <= 0 || K <= 0 || N <= 0) return 0;
+  return use_wide_m(N) ? band_workspace_bytes<512, 64>(uh_mp(B, H, W), N, K)
+                       : band_workspace_bytes<256, 128>(uh_mp(B, H, W), N, K);
 }
 
 extern "C" int uh_conv_gemm(int B, int H, int W, const void* a, int a_cstride, int a_coff, int K,
@@ -287,7 +742,10 @@ extern "C" int uh_conv_gemm_ws(int B, int H, int W, const void* a, int a_cstride
   hipStream_t st = (hipStream_t)s;
   if (T == 9) {
     UH_REQUIRE(((uintptr_t)workspace & 15) == 0, "conv_gemm: workspace must be 16-byte aligned");
-    uh_launch_band(p, workspace, workspace_bytes, st);
+    if (use_wide_m(N))
+      launch_band<512, 64>(p, workspace, workspace_bytes, st);
+    else
+      launch_band<256, 128>(p, workspace, workspace_bytes, st);
   } else if (use_wide_m(N)) {
     using C = Cfg<256, 64>;
     static bool attr = false;
