@@ -51,6 +51,86 @@ def cpu_baseline(threads):
             "sample": "4 images 3x256x256 per step (1/8 of the GPU batch), fp32, 1 warm-up + 3 timed steps, median"}
 
 
+PEAK_HBM = 8.0e12             # MI355X HBM3E, B/s
+CLDICE_BYTES_PER_PIXEL = 592   # both skeletons forward + the prediction's backward + the reductions, fp32, each plane once per pass
+
+
+def lunext_main(args):
+    """BASELINE configs[2]: LUNeXt 3x256x256, batch 32, soft_dice_cldice loss, one GPU.  The model's kernels are
+    HBM-bound; `roofline` prices the clDice loss (forward + backward) against the HBM peak."""
+    import torch
+    import unet_amd
+    from oracle import ref_cpu
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    torch.manual_seed(0)
+    model = unet_amd.LUNeXt(3, 1).to(dev).train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
+    crit = unet_amd.soft_dice_cldice()
+    x, m = ref_cpu.synth_batch(args.batch, 3, args.size, args.size)
+    x, m = x.to(dev), m.to(dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        probs = torch.sigmoid(model(x)).clamp(1e-6, 1 - 1e-6)         # training_utils.py:146
+        loss = crit(m, probs)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # the loss alone, forward + backward with respect to the probabilities
+    probs = torch.rand(args.batch, 1, args.size, args.size, device=dev).clamp(1e-6, 1 - 1e-6).requires_grad_(True)
+    for _ in range(3):
+        torch.autograd.grad(crit(m, probs), probs)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 20
+    e0.record()
+    for _ in range(reps):
+        torch.autograd.grad(crit(m, probs), probs)
+    e1.record()
+    torch.cuda.synchronize()
+    t_loss = e0.elapsed_time(e1) * 1e-3 / reps
+    pixels = args.batch * args.size * args.size
+    achieved = CLDICE_BYTES_PER_PIXEL * pixels / t_loss
+    out = {"metric": "train imgs/sec, LUNeXt 256^2 + clDice soft-skeleton loss, 1 MI355X", "value": round(args.batch * args.steps / dt, 2),
+           "unit": "img/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "bf16 storage / fp32 loss", "data": "synthetic",
+           "config": {"workload": f"LUNeXt 3x{args.size}x{args.size}, batch {args.batch}, soft_dice_cldice, fwd+bwd+Adam "
+                                  "(BASELINE configs[2])", "loss_last_step": round(loss.item(), 6)},
+           "roofline": {"bound": "hbm", "kernel": "clDice loss (soft-skeleton forward of both inputs + backward)",
+                        "achieved": round(achieved / 1e9, 1), "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+                        "frac": round(achieved / PEAK_HBM, 4), "traffic": None,
+                        "ms_per_call": round(t_loss * 1e3, 3), "bytes_per_pixel": CLDICE_BYTES_PER_PIXEL}}
+    if not args.no_cpu_baseline:
+        import torch.nn as nn  # noqa: F401
+        threads = int(os.environ.get("OMP_NUM_THREADS", min(16, os.cpu_count() or 1)))
+        torch.set_num_threads(threads)
+        torch.manual_seed(0)
+        ref = ref_cpu.RefLUNeXt(3, 1).train()
+        ropt = torch.optim.Adam(ref.parameters(), lr=1e-3)
+        rc = ref_cpu.RefSoftDiceClDice()
+        xs, ms = ref_cpu.synth_batch(8, 3, args.size, args.size)
+        times = []
+        for _ in range(3):
+            t1 = time.perf_counter()
+            ropt.zero_grad()
+            rc(ms, torch.sigmoid(ref(xs)).clamp(1e-6, 1 - 1e-6)).backward()
+            ropt.step()
+            times.append(time.perf_counter() - t1)
+        out["cpu_baseline"] = {"value": round(8 / sorted(times[1:])[0], 3), "unit": "img/s", "cores": threads, "kind": "port",
+                               "sample": "8 images 3x256x256 per step, fp32, 1 warm-up + 2 timed steps, best"}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -59,7 +139,11 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="images per GPU")
     ap.add_argument("--size", type=int, default=IMG)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["unet", "lunext"], default="unet",
+                    help="unet: BASELINE configs[1] (the contract line); lunext: configs[2], LUNeXt + clDice loss")
     args = ap.parse_args()
+    if args.workload == "lunext":
+        return lunext_main(args)
 
     import torch
     import torch.distributed as dist
@@ -114,6 +198,13 @@ def main():
         g = ks["conv_band"]
         achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12            # TFLOP/s over all conv_band_kernel launches
         scale = (args.size / IMG) ** 2
+        # HBM-side bytes per launch of the dominant kernel: measured separately with rocprofv3 PMC passes (the
+        # profiler cannot run inside this process); only valid for the default workload size
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tpath) and args.size == IMG and args.batch == BATCH_PER_GPU:
+            with open(tpath) as fh:
+                traffic = json.load(fh)["kernels"]["conv_band_kernel"]["traffic_bytes_per_launch"]
         out = {
             "metric": "train imgs/sec, UNet 256^2 bf16 fwd+bwd, 1/2/4/8 MI355X; % MFMA peak",
             "value": round(value, 2), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -126,7 +217,8 @@ def main():
             "step_mfma_frac": round(value / world * FLOP_PER_IMG_FWD_BWD * scale / PEAK_BF16_DENSE, 4),
             "roofline": {"bound": "mfma", "kernel": "conv_band_kernel (all 3x3 convolutions: 17 forward + 17 input-gradient launches per step)",
                          "achieved": round(achieved, 1), "peak": PEAK_BF16_DENSE / 1e12, "unit": "TFLOP/s",
-                         "frac": round(achieved * 1e12 / PEAK_BF16_DENSE, 4), "traffic": None,
+                         "frac": round(achieved * 1e12 / PEAK_BF16_DENSE, 4), "traffic": traffic,
+                         "traffic_unit": "bytes per launch (L2 memory-side reads + writes, profiles/r01_traffic.json)",
                          "launches_per_step": g["launches"] // instrumented, "event_timed_steps": instrumented,
                          "avg_launch_us": round(g["ms"] * 1e3 / g["launches"], 1),
                          "flop_per_launch": round(g["flops"] / g["launches"] / 1e9, 2)},
