@@ -42,6 +42,14 @@ int uh_pack_weights(const float* src, void* dst_bf16, int N, int T, int K,
                     long long sn, long long st, long long sk, long long on, long long ot,
                     int reverse, uh_stream s);
 
+/* The same repack for `count` tensors in one launch; the descriptors live in DEVICE memory (all fields 8 bytes). */
+typedef struct {
+  const float* src;
+  void* dst_bf16;
+  long long N, T, K, reverse, sn, st, sk, on, ot;
+} uh_pack_desc;
+int uh_pack_weights_multi(const uh_pack_desc* descs_device, int count, int blocks_per_desc, uh_stream s);
+
 /* ---- implicit-GEMM convolution (MFMA bf16, fp32 accumulate) ----------------------------
  * out[m][n] = sum_{t<T} sum_{k<K} a[m + off(t)][k] * w[n][t][k]   (T = 9: off = (ty-1)*(W+1)+(tx-1); T = 1: off = 0)
  * Replaces nn.Conv2d 3x3 pad 1 forward (unet.py:99-169), its input gradient (autograd of the same,

@@ -69,6 +69,32 @@ CONV_SHAPES = [  # B, H, W, Cin, Cout
 ]
 
 
+def test_pack_weights_multi_matches_single():
+    """one launch over a device-resident descriptor table == one uh_pack_weights call per tensor"""
+    g = torch.Generator().manual_seed(3)
+    specs = []   # (src, N, T, K, sn, st, sk, on, ot, reverse)
+    w1 = torch.randn(128, 64, 3, 3, generator=g).to(DEV)
+    w2 = torch.randn(256, 128, 2, 2, generator=g).to(DEV)          # transposed-conv layout [cin][w][2][2]
+    specs.append((w1, 128, 9, 64, 64 * 9, 1, 9, 9 * 64, 64, 0))
+    specs.append((w1, 64, 9, 128, 9, 1, 64 * 9, 9 * 128, 128, 1))
+    specs.append((w2, 128, 4, 256, 4, 1, 128 * 4, 256, 128 * 256, 0))
+    singles, rows, multis = [], [], []
+    for (src, N, T, K, sn, st, sk, on, ot, rev) in specs:
+        one = torch.zeros(N * T * K, dtype=torch.bfloat16, device=DEV)
+        call("uh_pack_weights", src.data_ptr(), one.data_ptr(), N, T, K, sn, st, sk, on, ot, rev, S())
+        many = torch.zeros(N * T * K, dtype=torch.bfloat16, device=DEV)
+        rows.append([src.data_ptr(), many.data_ptr(), N, T, K, rev, sn, st, sk, on, ot])
+        singles.append(one)
+        multis.append(many)
+    desc = torch.tensor(rows, dtype=torch.int64).to(DEV)
+    call("uh_pack_weights_multi", desc.data_ptr(), len(rows), 7, S())
+    torch.cuda.synchronize()
+    for one, many in zip(singles, multis):
+        assert torch.equal(one, many)
+    with pytest.raises(_lib.HipKernelError):
+        call("uh_pack_weights_multi", None, 1, 1, S())
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout", CONV_SHAPES)
 def test_conv_gemm_raw_stats(B, H, W, Cin, Cout):
     g = torch.Generator().manual_seed(B * 1000 + H * 10 + Cin)

@@ -22,6 +22,7 @@ SIGNATURES = {
     "uh_guard_rows": (I, [I]),
     "uh_rowmask_build": (I, [I, I, I, P, P]),
     "uh_pack_weights": (I, [P, P, I, I, I, L, L, L, L, L, I, P]),
+    "uh_pack_weights_multi": (I, [P, I, I, P]),
     "uh_conv_gemm": (I, [I, I, I, P, I, I, I, P, I, I, I, P, I, I, P, P, P, P, P, P]),
     "uh_conv_gemm_workspace": (Z, [I, I, I, I, I, I]),
     "uh_conv_gemm_ws": (I, [I, I, I, P, I, I, I, P, I, I, I, P, I, I, P, P, P, P, P, P, Z, P]),

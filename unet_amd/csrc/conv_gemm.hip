@@ -284,7 +284,6 @@ struct BandCfg {
 // workgroups waiting for each other.
 struct BandSched {
   int ntm, ntn, niter, G, aligned;
-  int ky_inner;   // iteration order inside a unit: 1 = (channel block, filter row), 0 = (filter row, channel block)
   float* ws;
 };
 
@@ -456,34 +455,21 @@ __global__ __launch_bounds__(512) void conv_band_kernel(GemmArgs p, BandSched sc
   int ky_n, kc_n;
   {
     const int it0 = (int)(i0 - (long long)u_n * niter);
-    if (sc.ky_inner) {
-      kc_n = it0 / 3;
-      ky_n = it0 % 3;
-    } else {
-      ky_n = it0 / KC;
-      kc_n = it0 % KC;
-    }
+    ky_n = it0 / KC;
+    kc_n = it0 % KC;
   }
   auto stage_offsets = [&]() {
     offA = ((long long)mt_n * BM + (long long)ky_n * p.Wp) * a_row_bytes + kc_n * 64;
     offB = (long long)nt_n * BN * b_row_bytes + ((long long)ky_n * 3 * p.K + kc_n * 32) * 2;
   };
   auto advance = [&]() {
-    bool unit_done;
-    if (sc.ky_inner) {
-      unit_done = false;
+    if (++kc_n == KC) {
+      kc_n = 0;
       if (++ky_n == 3) {
         ky_n = 0;
-        if (++kc_n == KC) { kc_n = 0; unit_done = true; }
-      }
-    } else {
-      unit_done = false;
-      if (++kc_n == KC) {
-        kc_n = 0;
-        if (++ky_n == 3) { ky_n = 0; unit_done = true; }
+        if (++nt_n == ntn) { nt_n = 0; ++mt_n; }
       }
     }
-    if (unit_done && ++nt_n == ntn) { nt_n = 0; ++mt_n; }
     stage_offsets();
   };
   stage_offsets();
@@ -673,11 +659,9 @@ static void launch_band(const GemmArgs& p, void* ws, size_t ws_bytes, hipStream_
   const long long units = (long long)sc.ntm * sc.ntn;
   sc.G = band_workgroups(units, sc.niter);
   sc.ws = (float*)ws;
-  // Measured (FETCH_SIZE, 32 x 64^2..256^2 images): with K >= 256 the filter-row-innermost order nearly halves
-  // the L2's memory-side reads (the re-read of a band by the next filter row still hits in L2) and is 2-4 %
-  // faster; with K <= 128 the channel-block-innermost order is the one with fewer memory-side reads (the two
-  // 64-byte halves of a line are staged back to back).
-  sc.ky_inner = (p.K >= 256) ? 1 : 0;
+  // (Iteration order inside a unit is filter row, then channel block.  The other order nearly halves the L2's
+  // memory-side reads for K >= 256 -- the next filter row's band still hits in L2 -- but was not faster inside
+  // the training step, and choosing the order at run time cost 25 % through the extra scalar code in the loop.)
   // even cuts need the workspace and cost a second launch plus ~2 x 128 KB of traffic per workgroup, and the
   // workgroups of a thinly populated last round run faster than those of a full one: measured, even cuts win
   // from about a third of the CU-time idle (137x4 and 37x8 tiles on 256 CUs), not at a fifth (529x2 tiles)

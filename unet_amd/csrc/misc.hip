@@ -68,6 +68,31 @@ extern "C" int uh_pack_weights(const float* src, void* dst, int N, int T, int K,
   return uh_check_launch("pack_weights");
 }
 
+// Many repacks in one launch: blockIdx.y selects the descriptor (device memory), blockIdx.x strides over its
+// elements.  A training step repacks every MFMA weight operand of the network twice (forward and rotated for
+// the input gradient); one launch per direction replaces ~20 launches of a few microseconds each.
+__global__ void pack_multi_kernel(const uh_pack_desc* __restrict__ descs) {
+  const uh_pack_desc d = descs[blockIdx.y];  // dst field: dst_bf16
+  const int N = (int)d.N, T = (int)d.T, K = (int)d.K;
+  const long long total = (long long)N * T * K;
+  const float* __restrict__ src = d.src;
+  bf16* __restrict__ dst = (bf16*)d.dst_bf16;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % K);
+    const long long r = i / K;
+    const int t = (int)(r % T);
+    const int n = (int)(r / T);
+    const int ts = d.reverse ? (T - 1 - t) : t;
+    dst[n * d.on + t * d.ot + k] = f2bf(src[n * d.sn + ts * d.st + k * d.sk]);
+  }
+}
+
+extern "C" int uh_pack_weights_multi(const uh_pack_desc* descs_device, int count, int blocks_per_desc, uh_stream s) {
+  UH_REQUIRE(descs_device && count > 0 && count <= 65535 && blocks_per_desc > 0, "pack_weights_multi: bad arguments");
+  hipLaunchKernelGGL(pack_multi_kernel, dim3(blocks_per_desc, count), dim3(256), 0, (hipStream_t)s, descs_device);
+  return uh_check_launch("pack_weights_multi");
+}
+
 // ---- space <-> depth for k2 s2 (transposed) convolutions -------------------------------------
 // Small geometry (B,H,W); large geometry (B,2H,2W).  One thread moves 8 channels of one
 // (small position, tap); every row of the destination, pads included, is written exactly once.

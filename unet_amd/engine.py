@@ -9,6 +9,7 @@ import torch
 from . import _lib
 from ._lib import call, EPI_RAW_STATS, EPI_AFFINE_RELU, EPI_MASKED, EPI_CONVT
 from .layout import pool_for
+from .packing import packer_for
 
 BN_EPS = 1e-5        # nn.BatchNorm2d defaults used by the reference (unet.py:20)
 BN_MOMENTUM = 0.1
@@ -53,6 +54,8 @@ class UNetRun:
         self.grad_alloc = self.on_ready = None
         self.timer = None          # optional KernelTimer (bench): times selected kernel launches with events
         self._ws, self._ws_bytes = None, 0
+        self.packer = packer_for(module, x.device)
+        self.wf = self.packer.get("fwd", _stream())       # packed forward operands, by layer name
 
     # ------------------------------------------------------------------ helpers
     def _gemm(self, *args):
@@ -76,11 +79,6 @@ class UNetRun:
         B, H, W, N, K, T = args[0], args[1], args[2], args[6], args[10], args[11]
         with self.timer.launch("conv_wgrad", 2.0 * B * H * W * K * N * T):
             call("uh_conv_wgrad", *args)
-
-    def _pack(self, w, N, T, K, sn, st, sk, on, ot, reverse=0):
-        dst = self.lease.bf16_flat(N * T * K)
-        call("uh_pack_weights", w.data_ptr(), dst.data_ptr(), N, T, K, sn, st, sk, on, ot, reverse, _stream())
-        return dst
 
     def _bn_params(self, C):
         f = self.lease.f32(4 * C)
@@ -118,7 +116,7 @@ class UNetRun:
                      conv.bias.data_ptr(), EPI_RAW_STATS, None, None, rec.y.ptr, rec.y.cstride, rec.y.coff,
                      stat.data_ptr(), s)
             else:
-                wp = self._pack(conv.weight, cout, 9, cin, cin * 9, 1, 9, 9 * cin, cin)
+                wp = self.wf[name]
                 parts = _lib.lib.uh_conv_gemm_mtiles(B, H, W, cout)
                 stat = self.lease.f32(parts * 2 * cout)
                 self._gemm(B, H, W, a_in.ptr, a_in.cstride, a_in.coff, cin, wp.data_ptr(), cout, 9,
@@ -136,7 +134,7 @@ class UNetRun:
                      conv.bias.data_ptr(), EPI_AFFINE_RELU, scale.data_ptr(), shift.data_ptr(), a_out.ptr,
                      a_out.cstride, a_out.coff, None, s)
             else:
-                wp = self._pack(conv.weight, cout, 9, cin, cin * 9, 1, 9, 9 * cin, cin)
+                wp = self.wf[name]
                 self._gemm(B, H, W, a_in.ptr, a_in.cstride, a_in.coff, cin, wp.data_ptr(), cout, 9,
                      EPI_AFFINE_RELU, a_out.ptr, a_out.cstride, a_out.coff, None, scale.data_ptr(),
                      shift.data_ptr(), None, self.masks[lvl].data_ptr(), s)
@@ -171,8 +169,7 @@ class UNetRun:
             w = WIDTHS[l]
             up = getattr(m, f"upconv{k}")
             Bs, Hs, Ws = self.geo[l + 1]
-            # W[ci][co][a][b] -> GEMM rows n = (a*2+b)*Cout + co
-            wp = self._pack(up.weight, w, 4, 2 * w, 4, 1, w * 4, 2 * w, w * 2 * w)
+            wp = self.wf[f"upconv{k}"]                        # GEMM rows n = (a*2+b)*Cout + co
             dst = cat[l].window(w, w)
             self._gemm(Bs, Hs, Ws, cur.ptr, cur.cstride, cur.coff, 2 * w, wp.data_ptr(), 4 * w, 1,
                  EPI_CONVT, dst.ptr, dst.cstride, dst.coff, up.bias.data_ptr(), None, None, None,
@@ -263,7 +260,7 @@ class UNetRun:
         if not want_dgrad:
             return None
         # dgrad: dx[m][ci] = sum_t sum_co dy[m + off(t)][co] * W[co][ci][8-t]
-        wd = self._pack(conv.weight, cin, 9, C, 9, 1, cin * 9, 9 * C, C, reverse=1)
+        wd = self.wb[name]
         dx = L.act(B, H, W, cin)
         self._gemm(B, H, W, dy.ptr, dy.cstride, dy.coff, C, wd.data_ptr(), cin, 9, EPI_MASKED,
              dx.ptr, dx.cstride, dx.coff, None, None, None, None, self.masks[lvl].data_ptr(), s)
@@ -280,6 +277,7 @@ class UNetRun:
             raise RuntimeError("backward through an eval-mode (running-statistics) forward is not built; "
                                "call model.train() before a forward pass that needs gradients")
         m, L, s = self.m, self.lease, _stream()
+        self.wb = self.packer.get("bwd", s)                # rotated / transposed operands of the input gradients
         grads = {}
         dl = dlogits.contiguous().float()
         oc = m.out_channels
@@ -332,7 +330,7 @@ class UNetRun:
             grads[f"upconv{k}.weight"] = dw
             self._ready(f"upconv{k}.weight", f"upconv{k}.bias")
             # input gradient: dx[m][ci] = sum_{t,co} d4[m][t*w+co] * W[ci][co][t]
-            wd = self._pack(up.weight, cin, 4, w, w * 4, 1, 4, 4 * w, w)
+            wd = self.wb[f"upconv{k}"]
             da = L.act(Bs, Hs, Ws, cin)
             self._gemm(Bs, Hs, Ws, d4.ptr, d4.cstride, d4.coff, 4 * w, wd.data_ptr(), cin, 1, EPI_MASKED,
                  da.ptr, da.cstride, da.coff, None, None, None, None, self.masks[l + 1].data_ptr(), s)

@@ -92,12 +92,13 @@ class UNet(nn.Module):
         self.sigmoid = nn.Sigmoid()
         self.intermediate_features = []
         self._last_run = None
+        self._packer = None               # packed bf16 operands (device buffers, not state)
 
     def __deepcopy__(self, memo):
         # copy.deepcopy(model) (k_fold.py:139): device buffers of the last pass are not state
         import copy
-        run, feats = self._last_run, self.intermediate_features
-        self._last_run, self.intermediate_features = None, []
+        run, feats, pk = self._last_run, self.intermediate_features, self._packer
+        self._last_run, self.intermediate_features, self._packer = None, [], None
         try:
             cls = self.__class__
             new = cls.__new__(cls)
@@ -105,7 +106,7 @@ class UNet(nn.Module):
             for k, v in self.__dict__.items():
                 setattr(new, k, copy.deepcopy(v, memo))
         finally:
-            self._last_run, self.intermediate_features = run, feats
+            self._last_run, self.intermediate_features, self._packer = run, feats, pk
         return new
 
     def forward(self, x):
