@@ -139,6 +139,8 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="images per GPU")
     ap.add_argument("--size", type=int, default=IMG)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only to rehearse "
+                    "the multi-rank path where RCCL cannot run, e.g. several ranks sharing one GPU)")
     ap.add_argument("--workload", choices=["unet", "lunext"], default="unet",
                     help="unet: BASELINE configs[1] (the contract line); lunext: configs[2], LUNeXt + clDice loss")
     args = ap.parse_args()
@@ -156,10 +158,15 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.backend != "nccl":
+        local = local % torch.cuda.device_count()          # rehearsal: ranks may share a GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    if world > 1 or os.environ.get("UNET_AMD_FORCE_COLLECTIVES") == "1":
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     torch.manual_seed(0)
     model = unet_amd.UNet(3, 1).to(dev)
@@ -230,7 +237,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(min(16, os.cpu_count() or 1) if "OMP_NUM_THREADS" not in os.environ
                                                else int(os.environ["OMP_NUM_THREADS"]))
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

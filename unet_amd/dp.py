@@ -14,6 +14,7 @@ with the remaining backward kernels.  xGMI is point-to-point, so buckets are few
 (>= 25 MB): per-link bandwidth, not latency, should set the cost.
 """
 import contextlib
+import os
 
 import torch
 import torch.distributed as dist
@@ -111,7 +112,10 @@ class DataParallelTrainer:
         self.buckets = GradBuckets(model, bucket_bytes)
         self.optimizer = torch.optim.Adam(model.parameters(), lr=lr, fused=True)   # training_utils.py:107
         self.timer = None
-        if self.world > 1:
+        # UNET_AMD_FORCE_COLLECTIVES=1 runs the broadcasts and all-reduces with a single rank too (a rehearsal
+        # of the RCCL calls on a one-GPU machine)
+        self.collectives = dist.is_initialized() and (self.world > 1 or os.environ.get("UNET_AMD_FORCE_COLLECTIVES") == "1")
+        if self.collectives:
             # same initial weights on every rank
             for p in model.parameters():
                 dist.broadcast(p.data, src=0, group=process_group)
@@ -130,7 +134,7 @@ class DataParallelTrainer:
             i = self.buckets.bucket_of[n]
             b = self.buckets.buckets[i]
             b["pending"].discard(n)
-            if not b["pending"] and self.world > 1 and "work" not in b:
+            if not b["pending"] and self.collectives and "work" not in b:
                 b["work"] = dist.all_reduce(b["tensor"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def train_step(self, images, masks, step_optimizer=True):
