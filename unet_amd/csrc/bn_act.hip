@@ -104,7 +104,7 @@ extern "C" int uh_bn_relu_apply(long long Mp, int C, const void* y, int y_cstrid
 }
 
 // ---- backward of relu(bn(y)) ------------------------------------------------------------------------
-extern "C" int uh_bn_bwd_parts(long long Mp, int C) { return (C > 0 && C % 8 == 0 && C / 8 <= 256) ? ew_blocks(Mp, C) : 0; }
+extern "C" int uh_bn_bwd_parts(long long Mp, int C) { return (C > 0 && C % 8 == 0 && C / 8 <= 256) ? ew_stat_blocks(Mp, C) : 0; }
 
 __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(long long Mp, int C, const char* __restrict__ da,
                                                                  int da_cs, int da_co, const char* __restrict__ y,
@@ -149,7 +149,7 @@ extern "C" int uh_bn_relu_bwd_reduce(long long Mp, int C, const void* da, int da
   EW_CHECK("bn_relu_bwd_reduce", C);
   UH_REQUIRE(Mp > 0 && da && y && mean && invstd && scale && shift && partial, "bn_relu_bwd_reduce: bad arguments");
   const int rpi = ew_rows_per_iter(C);
-  hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3(ew_blocks(Mp, C)), dim3(256), (size_t)rpi * 2 * C * 4,
+  hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3(ew_stat_blocks(Mp, C)), dim3(256), (size_t)rpi * 2 * C * 4,
                      (hipStream_t)s, Mp, C, (const char*)da, da_cstride, da_coff, (const char*)y, y_cstride, y_coff,
                      mean, invstd, scale, shift, partial);
   return uh_check_launch("bn_relu_bwd_reduce");
@@ -260,7 +260,7 @@ extern "C" int uh_colsum(long long Mp, int C, const void* x, int cstride, int co
   EW_CHECK("colsum", C);
   UH_REQUIRE(Mp > 0 && x && partial, "colsum: bad arguments");
   const int rpi = ew_rows_per_iter(C);
-  hipLaunchKernelGGL(colsum_kernel, dim3(ew_blocks(Mp, C)), dim3(256), (size_t)rpi * C * 4, (hipStream_t)s, Mp, C,
+  hipLaunchKernelGGL(colsum_kernel, dim3(ew_stat_blocks(Mp, C)), dim3(256), (size_t)rpi * C * 4, (hipStream_t)s, Mp, C,
                      (const char*)x, cstride, coff, partial);
   return uh_check_launch("colsum");
 }

@@ -92,6 +92,66 @@ __global__ __launch_bounds__(256) void skel_level_kernel(int planes, int H, int 
   }
 }
 
+// Same, four pixels of one row per thread (W % 4 == 0): the three rows of E_{k+1} are read as one aligned
+// 16-byte load plus the two neighbours each instead of nine scalar loads per pixel, and all index arithmetic
+// is 32-bit.  min/max are exact and order-independent, so the results equal the scalar kernel's bit for bit.
+template <bool CLAMP0>
+__global__ __launch_bounds__(256) void skel_level_v4_kernel(int planes, int H, int W, const float* __restrict__ ek,
+                                                            const float* __restrict__ ek1,
+                                                            const float* __restrict__ skel_prev,
+                                                            float* __restrict__ skel_out, float* __restrict__ ek2) {
+  const unsigned w4 = (unsigned)W >> 2;
+  const unsigned total = (unsigned)planes * H * w4;
+  for (unsigned it = blockIdx.x * 256u + threadIdx.x; it < total; it += gridDim.x * 256u) {
+    const unsigned xq = it % w4;
+    const unsigned row = it / w4;                       // plane * H + y
+    const int y = (int)(row % (unsigned)H);
+    const int x0 = (int)(xq << 2);
+    const size_t base = (size_t)row * W + x0;           // index of the first of the four pixels
+    float dmax[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    float emin[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+      if (y + dy < 0 || y + dy >= H) continue;
+      const float* r = ek1 + base + (long long)dy * W;
+      const f32x4 c = *(const f32x4*)r;
+      const float l = (x0 > 0) ? r[-1] : -INFINITY;
+      const float rr = (x0 + 4 < W) ? r[4] : -INFINITY;
+      const float v[6] = {l, c[0], c[1], c[2], c[3], rr};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        dmax[j] = fmaxf(dmax[j], fmaxf(fmaxf(v[j], v[j + 1]), v[j + 2]));
+        emin[j] = fminf(emin[j], v[j + 1]);
+      }
+      if (dy == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (j > 0 || x0 > 0) emin[j] = fminf(emin[j], v[j]);
+          if (j < 3 || x0 + 4 < W) emin[j] = fminf(emin[j], v[j + 2]);
+        }
+      }
+    }
+    f32x4 e = *(const f32x4*)(ek + base);
+    f32x4 sp = {0.f, 0.f, 0.f, 0.f};
+    if (skel_prev) sp = *(const f32x4*)(skel_prev + base);
+    f32x4 so;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float ev = e[j];
+      if (CLAMP0) ev = clamp01(ev);
+      const float delta = fmaxf(ev - dmax[j], 0.f);
+      float sv = delta;
+      if (skel_prev) {
+        const float prod = sp[j] * delta;
+        sv = sp[j] + fmaxf(delta - prod, 0.f);
+      }
+      so[j] = sv;
+    }
+    *(f32x4*)(skel_out + base) = so;
+    if (ek2) *(f32x4*)(ek2 + base) = f32x4{emin[0], emin[1], emin[2], emin[3]};
+  }
+}
+
 // ---- sums ---------------------------------------------------------------------------------------------------
 // partial[blk][7] = (sum t*p, sum t, sum p, sum skel_p*t, sum skel_p, sum skel_t*p, sum skel_t), t,p clamped
 __global__ __launch_bounds__(256) void cldice_sums_kernel(long long n, const float* __restrict__ yt,
@@ -353,6 +413,10 @@ extern "C" int uh_soft_dilate(int planes, int H, int W, const float* in, float* 
 static int skel_forward(int planes, int H, int W, const float* x, float* E, float* SK, int keep_all, hipStream_t st) {
   const long long n = (long long)planes * H * W;
   const int grid = grid_for(n);
+  // four pixels per thread when rows are multiples of 4 pixels, every plane set is 16-byte aligned and the
+  // item count fits 32 bits
+  const bool vec4 = (W % 4 == 0) && n / 4 < 0x7fffffffLL && (((uintptr_t)x | (uintptr_t)E | (uintptr_t)SK) & 15) == 0;
+  const int grid4 = (int)((n / 4 + 255) / 256);
   auto eptr = [&](int k) -> float* { return keep_all ? E + (long long)(k - 1) * n : E + (long long)((k - 1) % 3) * n; };
   auto sptr = [&](int k) -> float* { return keep_all ? SK + (long long)k * n : SK; };
   hipLaunchKernelGGL((morph_kernel<true, false>), dim3(grid), dim3(256), 0, st, planes, H, W, x, eptr(1));
@@ -360,10 +424,16 @@ static int skel_forward(int planes, int H, int W, const float* x, float* E, floa
     const float* ek = (k == 0) ? x : eptr(k);
     float* ek2 = (k + 1 < SKEL_LEVELS) ? eptr(k + 2) : nullptr;
     const float* sp = (k == 0) ? nullptr : sptr(k - 1);
-    if (k == 0)
+    if (vec4) {
+      if (k == 0)
+        hipLaunchKernelGGL((skel_level_v4_kernel<true>), dim3(grid4), dim3(256), 0, st, planes, H, W, ek, eptr(k + 1), sp, sptr(k), ek2);
+      else
+        hipLaunchKernelGGL((skel_level_v4_kernel<false>), dim3(grid4), dim3(256), 0, st, planes, H, W, ek, eptr(k + 1), sp, sptr(k), ek2);
+    } else if (k == 0) {
       hipLaunchKernelGGL((skel_level_kernel<true>), dim3(grid), dim3(256), 0, st, planes, H, W, ek, eptr(k + 1), sp, sptr(k), ek2);
-    else
+    } else {
       hipLaunchKernelGGL((skel_level_kernel<false>), dim3(grid), dim3(256), 0, st, planes, H, W, ek, eptr(k + 1), sp, sptr(k), ek2);
+    }
   }
   return uh_check_launch("soft_skel");
 }

@@ -11,6 +11,16 @@ static inline int ew_blocks(long long Mp, int C) {
   if (b > 2048) b = 2048;
   return (int)b;
 }
+// Workgroups of a kernel that ends in block_combine_store: the combine (an LDS round trip and NSTAT*C floats of
+// partial output per workgroup) is paid once per workgroup, so every workgroup gets at least eight row groups.
+static inline int ew_stat_blocks(long long Mp, int C) {
+  const int rpi = ew_rows_per_iter(C);
+  const long long iters = (Mp + rpi - 1) / rpi;
+  long long b = (iters + 7) / 8;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (int)b;
+}
 #define EW_CHECK(name, C)                                                                              \
   UH_REQUIRE((C) > 0 && (C) % 8 == 0 && (C) / 8 <= 256, name ": C=%d must be a multiple of 8, at most 2048", (C))
 

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(long long Mp, int C, in
   if (mode == UH_EPI_RAW_STATS) block_combine_store<2>(acc, C, cpr, rpi, lds, partial + (long long)blockIdx.x * 2 * C);
 }
 
-extern "C" int uh_dw_parts(long long Mp, int C) { return (C > 0 && C % 8 == 0 && C / 8 <= 256) ? ew_blocks(Mp, C) : 0; }
+extern "C" int uh_dw_parts(long long Mp, int C) { return (C > 0 && C % 8 == 0 && C / 8 <= 256) ? ew_stat_blocks(Mp, C) : 0; }
 
 extern "C" int uh_dwconv3x3_fwd(int B, int H, int W, int C, const void* x, int x_cstride, int x_coff,
                                 const float* w9, const float* bias, int mode, const float* scale, const float* shift,
@@ -84,7 +84,7 @@ extern "C" int uh_dwconv3x3_fwd(int B, int H, int W, int C, const void* x, int x
   UH_REQUIRE(mode != UH_EPI_AFFINE_RELU || (scale && shift), "dwconv3x3_fwd: AFFINE_RELU needs scale/shift");
   const long long Mp = uh_mp(B, H, W);
   const int rpi = ew_rows_per_iter(C);
-  hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(ew_blocks(Mp, C)), dim3(256), (size_t)rpi * 2 * C * 4, (hipStream_t)s, Mp,
+  hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(ew_stat_blocks(Mp, C)), dim3(256), (size_t)rpi * 2 * C * 4, (hipStream_t)s, Mp,
                      C, W + 1, (const char*)x, x_cstride, x_coff, w9, bias, mode, scale, shift, rowmask, (char*)out,
                      o_cstride, o_coff, partial);
   return uh_check_launch("dwconv3x3_fwd");
@@ -175,7 +175,7 @@ extern "C" int uh_bn_res_relu_bwd_reduce(long long Mp, int C, const void* da, in
   EW_CHECK("bn_res_relu_bwd_reduce", C);
   UH_REQUIRE(Mp > 0 && da && y && x && mean && invstd && scale && shift && partial, "bn_res_relu_bwd_reduce: bad arguments");
   const int rpi = ew_rows_per_iter(C);
-  hipLaunchKernelGGL(bn_res_relu_bwd_reduce_kernel, dim3(ew_blocks(Mp, C)), dim3(256), (size_t)rpi * 2 * C * 4,
+  hipLaunchKernelGGL(bn_res_relu_bwd_reduce_kernel, dim3(ew_stat_blocks(Mp, C)), dim3(256), (size_t)rpi * 2 * C * 4,
                      (hipStream_t)s, Mp, C, (const char*)da, da_cstride, da_coff, (const char*)y, y_cstride, y_coff,
                      (const char*)x, x_cstride, x_coff, mean, invstd, scale, shift, partial);
   return uh_check_launch("bn_res_relu_bwd_reduce");
@@ -333,7 +333,7 @@ extern "C" int uh_dwconv3x3_wgrad(int B, int H, int W, int C, const void* dy, in
   UH_REQUIRE(B > 0 && H > 0 && W > 0 && dy && x && partial, "dwconv3x3_wgrad: bad arguments");
   const long long Mp = uh_mp(B, H, W);
   const int rpi = ew_rows_per_iter(C);
-  hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3(ew_blocks(Mp, C)), dim3(256), (size_t)rpi * C * 4, (hipStream_t)s, Mp, C,
+  hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3(ew_stat_blocks(Mp, C)), dim3(256), (size_t)rpi * C * 4, (hipStream_t)s, Mp, C,
                      W + 1, (const char*)dy, dy_cstride, dy_coff, (const char*)x, x_cstride, x_coff, partial);
   return uh_check_launch("dwconv3x3_wgrad");
 }
