@@ -39,16 +39,10 @@ struct Cfg {
   static constexpr int A_BYTES = BM * 128;
   static constexpr int B_BYTES = BN * 128;
   static constexpr int STAGE = A_BYTES + B_BYTES;
-  static constexpr int PITCH = BN * 2 + 16;               // epilogue tile row pitch (bytes)
-  static constexpr int TILE_BYTES = BM * PITCH;
-  static constexpr int FLAG_OFF = TILE_BYTES;             // float[BM]
-  static constexpr int RED_OFF = FLAG_OFF + BM * 4;       // float[WM][2][BN]
-  static constexpr int EPI_BYTES = RED_OFF + WM * 2 * BN * 4;
-  static constexpr int LDS_BYTES = 2 * STAGE;
-  static_assert(EPI_BYTES <= LDS_BYTES, "epilogue reuses the staging LDS");
+  static constexpr int LDS_BYTES = 2 * STAGE;             // the epilogue's float[WM][2][BN] reuses it
 };
 
-template <int BM, int BN>
+template <int BM, int BN, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmArgs p) {
   using C = Cfg<BM, BN>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -68,13 +62,21 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmArgs p) {
   const long long a_row_bytes = (long long)p.a_cstride * 2;
   const long long b_row_bytes = (long long)p.T * p.K * 2;
   const char* a_lane = p.A + (m0 + 8 * wave + lrow) * a_row_bytes + (long long)p.a_coff * 2 + src_chunk * 16;
-  const char* b_lane = p.Wt + (long long)(n0 + 8 * wave + lrow) * b_row_bytes + src_chunk * 16;
+  // Weight rows are staged in permuted order: LDS row w*64 + j*16 + c holds output column w*64 + c*4 + j, so the
+  // four accumulator tiles j = 0..3 a lane holds for one row of A are four ADJACENT columns (8-byte stores).
+  const char* b_lane[BN / 32];
+#pragma unroll
+  for (int jj = 0; jj < BN / 32; ++jj) {
+    const int r = 8 * wave + lrow + 32 * jj;
+    const int col = (r & ~63) + (r & 15) * 4 + ((r >> 4) & 3);
+    b_lane[jj] = p.Wt + (long long)(n0 + col) * b_row_bytes + src_chunk * 16;
+  }
 
   auto stage = [&](int buf, int tap, int kc) {
     int off = 0;
     if (p.T == 9) off = (tap / 3 - 1) * p.Wp + (tap % 3 - 1);
     const char* as = a_lane + (long long)off * a_row_bytes + kc * 128;
-    const char* bs = b_lane + ((long long)tap * p.K + kc * 64) * 2;
+    const long long boff = ((long long)tap * p.K + kc * 64) * 2;
     char* lds = smem + buf * C::STAGE + wave * 1024;
 #pragma unroll
     for (int j = 0; j < BM / 32; ++j)
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmArgs p) {
                                        (UH_LDS void*)(lds + j * 4096), 16, 0, 0);
 #pragma unroll
     for (int j = 0; j < BN / 32; ++j)
-      __builtin_amdgcn_global_load_lds((const UH_GLOBAL void*)(bs + j * 32 * b_row_bytes),
+      __builtin_amdgcn_global_load_lds((const UH_GLOBAL void*)(b_lane[j] + boff),
                                        (UH_LDS void*)(lds + C::A_BYTES + j * 4096), 16, 0, 0);
   };
 
@@ -125,110 +127,107 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmArgs p) {
     }
   }
 
-  // ---- epilogue -----------------------------------------------------------------------------
+  // ---- epilogue: straight from the accumulators ------------------------------------------------------------
+  // lane (l15, g) holds rows wm*64 + i*16 + g*4 + e and the 4 adjacent columns n0 + wn*64 + l15*4 + j
   __syncthreads();  // every wave is done reading the staging buffers
-  float* flag = (float*)(smem + C::FLAG_OFF);
-  float* red = (float*)(smem + C::RED_OFF);
-  if (tid < BM) {
-    const long long m = m0 + tid;
-    flag[tid] = (m < p.Mp && p.rowmask[m]) ? 1.f : 0.f;
+  float* red = (float*)smem;                       // [WM][2][BN]
+  const int ncol = wn * 64 + l15 * 4;
+  const int n = n0 + ncol;
+  float cb[4] = {0.f, 0.f, 0.f, 0.f}, csc[4] = {1.f, 1.f, 1.f, 1.f};
+  int otap = 0, co = n;
+  if (MODE == UH_EPI_CONVT) {
+    otap = n / p.Cout;
+    co = n - otap * p.Cout;
+    if (p.bias && otap < 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) cb[j] = p.bias[co + j];
+    }
+  } else if (MODE == UH_EPI_AFFINE_RELU) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { csc[j] = p.scale[n + j]; cb[j] = p.shift[n + j]; }
+  } else if (p.bias) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cb[j] = p.bias[n + j];
   }
-  __syncthreads();
-
+  const long long mask_last_dword = (p.Mp - 1) >> 2;
+  const long long o_row_bytes = (long long)p.o_cstride * 2;
+  const int Hp = p.H + 1, Wp = p.W + 1;
+  const int oHp = 2 * p.H + 1, oWp = 2 * p.W + 1;
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int col = wn * 64 + j * 16 + l15;
-    const int n = n0 + col;
-    float bias = 0.f, sc = 1.f, sh = 0.f;
-    if (p.mode == UH_EPI_CONVT) {
-      bias = p.bias ? p.bias[n % p.Cout] : 0.f;
-    } else if (p.mode == UH_EPI_AFFINE_RELU) {
-      sc = p.scale[n];
-      sh = p.shift[n];
-    } else {
-      bias = p.bias ? p.bias[n] : 0.f;
+  for (int i = 0; i < 4; ++i) {
+    const long long mrow = m0 + wm * 64 + i * 16 + g * 4;          // first of the lane's four rows (multiple of 4)
+    long long d = mrow >> 2;
+    if (d > mask_last_dword) d = mask_last_dword;
+    const uint32_t fw = *(const uint32_t*)(p.rowmask + 4 * d);
+    // transposed conv: position of row mrow in the input geometry, stepped row by row
+    int x = 0, y = 0;
+    long long b = 0;
+    if (MODE == UH_EPI_CONVT) {
+      x = (int)(mrow % Wp);
+      const long long r = mrow / Wp;
+      y = (int)(r % Hp);
+      b = r / Hp;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int rbase = wm * 64 + i * 16 + g * 4;
-      const f32x4 f = *(const f32x4*)(flag + rbase);
+    for (int e = 0; e < 4; ++e) {
+      const long long m = mrow + e;
+      const float f = (m < p.Mp) ? (float)((fw >> (8 * e)) & 0xffu) : 0.f;
+      float v[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float v = acc[i][j][e];
-        if (p.mode == UH_EPI_AFFINE_RELU) {
-          v = fmaxf(v * sc + sh, 0.f);
-        } else {
-          v += bias;
+      for (int j = 0; j < 4; ++j) {
+        float t = acc[i][j][e];
+        if (MODE == UH_EPI_AFFINE_RELU) t = fmaxf(t * csc[j] + cb[j], 0.f);
+        else t += cb[j];
+        t *= f;
+        if (MODE == UH_EPI_RAW_STATS) {
+          s1[j] += t;
+          s2[j] += t * t;
         }
-        v *= f[e];
-        if (p.mode == UH_EPI_RAW_STATS) {
-          s1[j] += v;
-          s2[j] += v * v;
+        v[j] = t;
+      }
+      uint2 o;
+      o.x = (MODE == UH_EPI_RAW_STATS) ? pack2h(v[0], v[1]) : pack2(v[0], v[1]);
+      o.y = (MODE == UH_EPI_RAW_STATS) ? pack2h(v[2], v[3]) : pack2(v[2], v[3]);
+      if (MODE == UH_EPI_CONVT) {
+        // column n = tap*Cout + co of input position (b,y,x) goes to output position (b, 2y + tap/2, 2x + tap%2),
+        // channel co; output geometry (B, 2H, 2W); tap >= 4: zero-padded weight rows (N > 4*Cout)
+        const int Y = 2 * y + (otap >> 1), X = 2 * x + (otap & 1);
+        if (m < p.Mp && otap < 4 && Y < oHp && X < oWp) {
+          const long long om = (b * oHp + Y) * oWp + X;
+          *(uint2*)(p.out + (om * p.o_cstride + p.o_coff + co) * 2) = o;
         }
-        if (p.mode == UH_EPI_RAW_STATS)
-          *(_Float16*)(smem + (rbase + e) * C::PITCH + col * 2) = f2h(v);   // BatchNorm input: fp16
-        else
-          *(bf16*)(smem + (rbase + e) * C::PITCH + col * 2) = f2bf(v);
+        if (++x == Wp) {
+          x = 0;
+          if (++y == Hp) { y = 0; ++b; }
+        }
+      } else if (m < p.Mp) {
+        *(uint2*)(p.out + m * o_row_bytes + (long long)(p.o_coff + n) * 2) = o;
       }
     }
   }
-  if (p.mode == UH_EPI_RAW_STATS) {
+  if (MODE == UH_EPI_RAW_STATS) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       s1[j] += __shfl_xor(s1[j], 16, 64);
       s1[j] += __shfl_xor(s1[j], 32, 64);
       s2[j] += __shfl_xor(s2[j], 16, 64);
       s2[j] += __shfl_xor(s2[j], 32, 64);
-      if (g == 0) {
-        const int col = wn * 64 + j * 16 + l15;
-        red[(wm * 2 + 0) * BN + col] = s1[j];
-        red[(wm * 2 + 1) * BN + col] = s2[j];
+    }
+    if (g == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        red[(wm * 2 + 0) * BN + ncol + j] = s1[j];
+        red[(wm * 2 + 1) * BN + ncol + j] = s2[j];
       }
     }
-  }
-  __syncthreads();
-
-  if (p.mode == UH_EPI_RAW_STATS && tid < 2 * BN) {
-    const int which = tid / BN, col = tid % BN;
-    float v = 0.f;
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const int which = tid / BN, col = tid % BN;
+      float v = 0.f;
 #pragma unroll
-    for (int w = 0; w < C::WM; ++w) v += red[(w * 2 + which) * BN + col];
-    p.stat_partial[((long long)blockIdx.x * 2 + which) * p.N + n0 + col] = v;
-  }
-
-  constexpr int CPR = BN / 8;  // 16-byte chunks per tile row
-  if (p.mode != UH_EPI_CONVT) {
-#pragma unroll
-    for (int q = tid; q < BM * CPR; q += 256) {
-      const int row = q / CPR, cc = q % CPR;
-      const long long m = m0 + row;
-      if (m < p.Mp) {
-        const U4 v = *(const U4*)(smem + row * C::PITCH + cc * 16);
-        *(U4*)(p.out + (m * p.o_cstride + p.o_coff + n0 + cc * 8) * 2) = v;
-      }
-    }
-  } else {
-    // transposed conv k2 s2: column n = tap*Cout + co of input position (b,y,x) goes to
-    // output position (b, 2y + tap/2, 2x + tap%2), channel co; output geometry (B, 2H, 2W).
-    const int Hp = p.H + 1, Wp = p.W + 1;
-    const int oHp = 2 * p.H + 1, oWp = 2 * p.W + 1;
-    for (int q = tid; q < BM * CPR; q += 256) {
-      const int row = q / CPR, cc = q % CPR;
-      const long long m = m0 + row;
-      if (m >= p.Mp) continue;
-      const int n = n0 + cc * 8;
-      const int t = n / p.Cout, co = n % p.Cout;
-      const int x = (int)(m % Wp);
-      const long long r = m / Wp;
-      const int y = (int)(r % Hp);
-      const long long b = r / Hp;
-      const int Y = 2 * y + (t >> 1), X = 2 * x + (t & 1);
-      if (t < 4 && Y < oHp && X < oWp) {        // t >= 4: zero-padded weight rows (N > 4*Cout)
-        const U4 v = *(const U4*)(smem + row * C::PITCH + cc * 16);
-        const long long om = (b * oHp + Y) * oWp + X;
-        *(U4*)(p.out + (om * p.o_cstride + p.o_coff + co) * 2) = v;
-      }
+      for (int w = 0; w < C::WM; ++w) v += red[(w * 2 + which) * BN + col];
+      p.stat_partial[((long long)blockIdx.x * 2 + which) * p.N + n0 + col] = v;
     }
   }
 }
@@ -673,6 +672,28 @@ static void launch_band(const GemmArgs& p, void* ws, size_t ws_bytes, hipStream_
   else launch_band_mode<BM, BN, UH_EPI_MASKED>(p, sc, st);
 }
 
+template <int BM, int BN, int MODE>
+static void launch_tile_mode(const GemmArgs& p, hipStream_t st) {
+  using C = Cfg<BM, BN>;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)conv_gemm_kernel<BM, BN, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    attr = true;
+  }
+  dim3 grid((unsigned)((p.Mp + BM - 1) / BM), p.N / BN);
+  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, MODE>), grid, dim3(256), C::LDS_BYTES, st, p);
+}
+
+template <int BM, int BN>
+static void launch_tile(const GemmArgs& p, hipStream_t st) {
+  switch (p.mode) {
+    case UH_EPI_RAW_STATS: launch_tile_mode<BM, BN, UH_EPI_RAW_STATS>(p, st); break;
+    case UH_EPI_AFFINE_RELU: launch_tile_mode<BM, BN, UH_EPI_AFFINE_RELU>(p, st); break;
+    case UH_EPI_MASKED: launch_tile_mode<BM, BN, UH_EPI_MASKED>(p, st); break;
+    default: launch_tile_mode<BM, BN, UH_EPI_CONVT>(p, st); break;
+  }
+}
+
 static bool use_wide_m(int N) { return N % 128 != 0; }  // N = 64, 192, ...: tiles 64 wide
 
 // M tiles of the T = 9 path (rows of stat_partial in RAW_STATS mode)
@@ -712,6 +733,8 @@ extern "C" int uh_conv_gemm_ws(int B, int H, int W, const void* a, int a_cstride
   UH_REQUIRE(o_cstride % 8 == 0 && o_coff % 8 == 0, "conv_gemm: bad out view");
   if (mode == UH_EPI_CONVT) {
     UH_REQUIRE(o_cstride - o_coff >= 8, "conv_gemm: bad transposed-conv view");
+    UH_REQUIRE(((N / 4 < o_cstride - o_coff) ? N / 4 : o_cstride - o_coff) % 4 == 0,
+               "conv_gemm: transposed conv needs an output channel count that is a multiple of 4");
     UH_REQUIRE(T == 1, "conv_gemm: transposed conv is a T=1 GEMM");
   } else {
     UH_REQUIRE(o_cstride >= o_coff + N, "conv_gemm: out view too narrow");
@@ -750,23 +773,9 @@ extern "C" int uh_conv_gemm_ws(int B, int H, int W, const void* a, int a_cstride
     else
       launch_band<256, 128>(p, workspace, workspace_bytes, st);
   } else if (use_wide_m(N)) {
-    using C = Cfg<256, 64>;
-    static bool attr = false;
-    if (!attr) {
-      (void)hipFuncSetAttribute((const void*)conv_gemm_kernel<256, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-      attr = true;
-    }
-    dim3 grid((unsigned)((p.Mp + 255) / 256), N / 64);
-    hipLaunchKernelGGL((conv_gemm_kernel<256, 64>), grid, dim3(256), C::LDS_BYTES, st, p);
+    launch_tile<256, 64>(p, st);
   } else {
-    using C = Cfg<128, 128>;
-    static bool attr = false;
-    if (!attr) {
-      (void)hipFuncSetAttribute((const void*)conv_gemm_kernel<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-      attr = true;
-    }
-    dim3 grid((unsigned)((p.Mp + 127) / 128), N / 128);
-    hipLaunchKernelGGL((conv_gemm_kernel<128, 128>), grid, dim3(256), C::LDS_BYTES, st, p);
+    launch_tile<128, 128>(p, st);
   }
   return uh_check_launch("conv_gemm");
 }
