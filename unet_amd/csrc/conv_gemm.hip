@@ -275,20 +275,24 @@ struct BandCfg {
 
 // How the work of one launch is cut.  A "unit" is one BM x BN output tile (unit u: M tile u / ntn, N tile
 // u % ntn) and takes niter = 3*K/32 iterations; the launch is the sequence of all (unit, iteration) pairs and
-// workgroup position p takes the contiguous piece [band_start(p), band_start(p+1)).  With `aligned` the cuts
-// fall on unit boundaries (whole tiles per workgroup, uneven when units % G != 0).  Otherwise the cuts are
-// even in iterations: a piece that covers only part of a unit leaves its accumulators in `ws`
-// (slot 2p: the piece starts inside the unit, slot 2p+1: it ends inside), and conv_band_fixup_kernel sums
-// the pieces of every cut unit in position order and runs the epilogue -- a second launch instead of
-// workgroups waiting for each other.
+// workgroup position p takes a list of them.  With `aligned` a workgroup takes whole units: the 8 XCDs split
+// the units into 8 contiguous ranges, and inside a range workgroup j takes units j, j + G/8, j + 2G/8, ... so that
+// the workgroups that run at the same time on one XCD work on NEIGHBOURING tiles (the bands of neighbouring M
+// tiles overlap and all N tiles of an M tile read the same rows: their re-reads then hit in that XCD's L2).
+// Whole units are uneven when units % G != 0; otherwise (`aligned` = 0) position p takes the contiguous piece
+// [band_start(p), band_start(p+1)) of the (unit, iteration) sequence, cut evenly in iterations: a piece that
+// covers only part of a unit leaves its accumulators in `ws` (slot 2p: the piece starts inside the unit,
+// slot 2p+1: it ends inside), and conv_band_fixup_kernel sums the pieces of every cut unit in position order
+// and runs the epilogue -- a second launch instead of workgroups waiting for each other.
 struct BandSched {
   int ntm, ntn, niter, G, aligned;
+  int upx;        // aligned: units per XCD range
   float* ws;
 };
 
 __device__ __forceinline__ long long band_start(const BandSched& sc, int pos) {
   const long long units = (long long)sc.ntm * sc.ntn;
-  return sc.aligned ? ((long long)pos * units / sc.G) * sc.niter : ((long long)pos * units * sc.niter) / sc.G;
+  return ((long long)pos * units * sc.niter) / sc.G;
 }
 
 // Epilogue of one unit, straight from the accumulators: lane (l15, g) of wave (wm, wn) holds rows
@@ -377,10 +381,25 @@ __global__ __launch_bounds__(512) void conv_band_kernel(GemmArgs p, BandSched sc
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // workgroups b, b+8, ... share an XCD: give each XCD one contiguous run of positions
   const int pos = (blockIdx.x & 7) * (sc.G >> 3) + (blockIdx.x >> 3);
-  const long long i0 = band_start(sc, pos), i1 = band_start(sc, pos + 1);
-  if (i0 >= i1) return;
-  const int total = (int)(i1 - i0);
   const int niter = sc.niter, ntn = sc.ntn;
+  // this workgroup's units: u_first, u_first + u_step, ...; `total` iterations, starting at iteration it_first
+  // of the first unit
+  int u_first, u_step, it_first, total;
+  if (sc.aligned) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int u_end = min((xcd + 1) * sc.upx, sc.ntm * ntn);
+    u_first = xcd * sc.upx + j;
+    u_step = sc.G >> 3;
+    it_first = 0;
+    total = (u_first < u_end) ? ((u_end - u_first + u_step - 1) / u_step) * niter : 0;
+  } else {
+    const long long i0 = band_start(sc, pos), i1 = band_start(sc, pos + 1);
+    u_first = (int)(i0 / niter);
+    u_step = 1;
+    it_first = (int)(i0 - (long long)u_first * niter);
+    total = (int)(i1 - i0);
+  }
+  if (total <= 0) return;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -449,14 +468,9 @@ __global__ __launch_bounds__(512) void conv_band_kernel(GemmArgs p, BandSched sc
   //   wait.  Its buffer was last read in phase 2 of s-3, whose reads each wave has waited for before the
   //   barriers that precede phase 1 of s-2.
   long long offA, offB;
-  int u_n = (int)(i0 / niter);
+  int u_n = u_first;
   int mt_n = u_n / ntn, nt_n = u_n % ntn;
-  int ky_n, kc_n;
-  {
-    const int it0 = (int)(i0 - (long long)u_n * niter);
-    ky_n = it0 / KC;
-    kc_n = it0 % KC;
-  }
+  int ky_n = it_first / KC, kc_n = it_first % KC;
   auto stage_offsets = [&]() {
     offA = ((long long)mt_n * BM + (long long)ky_n * p.Wp) * a_row_bytes + kc_n * 64;
     offB = (long long)nt_n * BN * b_row_bytes + ((long long)ky_n * 3 * p.K + kc_n * 32) * 2;
@@ -466,7 +480,9 @@ __global__ __launch_bounds__(512) void conv_band_kernel(GemmArgs p, BandSched sc
       kc_n = 0;
       if (++ky_n == 3) {
         ky_n = 0;
-        if (++nt_n == ntn) { nt_n = 0; ++mt_n; }
+        u_n += u_step;
+        mt_n = u_n / ntn;
+        nt_n = u_n - mt_n * ntn;
       }
     }
     stage_offsets();
@@ -488,12 +504,10 @@ __global__ __launch_bounds__(512) void conv_band_kernel(GemmArgs p, BandSched sc
 
   int buf = 0, s = 0;
   int pend_mt = -1, pend_nt = 0;                // unit whose BatchNorm sums still sit in red[]
-  long long i = i0;
+  int u = u_first, it_a = it_first;
   bf16x8 af[4], bfr[4];
-  while (i < i1) {
-    const int u = (int)(i / niter);
-    const int it_a = (int)(i - (long long)u * niter);
-    const int cnt = min(niter - it_a, (int)(i1 - i));
+  while (s < total) {
+    const int cnt = min(niter - it_a, total - s);
     const bool full = (it_a == 0 && cnt == niter);
     const int mt = u / ntn, nt = u - mt * ntn;
     f32x4 acc[4][4];
@@ -551,7 +565,6 @@ __global__ __launch_bounds__(512) void conv_band_kernel(GemmArgs p, BandSched sc
       }
       buf = buf1;
     }
-    i += cnt;
 
     if (full) {
       uint32_t fw[4];
@@ -567,6 +580,8 @@ __global__ __launch_bounds__(512) void conv_band_kernel(GemmArgs p, BandSched sc
 #pragma unroll
         for (int j = 0; j < 4; ++j) slot[(ii * 4 + j) * 512] = acc[ii][j];
     }
+    u += u_step;
+    it_a = 0;
   }
   if (wave < 4) __builtin_amdgcn_s_barrier();   // match the second half's extra barrier
   if (MODE == UH_EPI_RAW_STATS && pend_mt >= 0) {
@@ -658,6 +673,7 @@ static void launch_band(const GemmArgs& p, void* ws, size_t ws_bytes, hipStream_
   const long long units = (long long)sc.ntm * sc.ntn;
   sc.G = band_workgroups(units, sc.niter);
   sc.ws = (float*)ws;
+  sc.upx = (int)((units + 7) / 8);
   // (Iteration order inside a unit is filter row, then channel block.  The other order nearly halves the L2's
   // memory-side reads for K >= 256 -- the next filter row's band still hits in L2 -- but was not faster inside
   // the training step, and choosing the order at run time cost 25 % through the extra scalar code in the loop.)
