@@ -22,6 +22,8 @@ struct WgradArgs {
   long long rows_per_split;  // multiple of 128
   int dy_cstride, dy_coff, a_cstride, a_coff;
   int N, K, Wp;
+  int S;        // pixel splits
+  int remap;    // 1: 1-D grid, every split's tiles on one XCD (see the kernel)
 };
 
 template <int T>
@@ -41,8 +43,24 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
-  const int split = blockIdx.z;
+  // All (n, k) tiles of one pixel split read the same rows of dY and A.  Workgroups are dealt to the 8 XCDs
+  // round-robin by their linear id, so with a 1-D grid decoded as id -> (xcd = id % 8, q = id / 8),
+  // split = xcd + 8 * (q / tiles), tile = q % tiles, the tiles of a split run on ONE XCD, next to each other
+  // in time, and those rows are fetched into one L2 once instead of into all eight.
+  int n0, k0, split;
+  if (p.remap) {
+    const int tn = p.N / 64, tiles = tn * (p.K / 64);
+    const int q = blockIdx.x >> 3;
+    split = (blockIdx.x & 7) + 8 * (q / tiles);
+    if (split >= p.S) return;
+    const int t = q % tiles;
+    n0 = (t % tn) * 64;
+    k0 = (t / tn) * 64;
+  } else {
+    n0 = blockIdx.x * 64;
+    k0 = blockIdx.y * 64;
+    split = blockIdx.z;
+  }
   const long long ms = (long long)split * p.rows_per_split;
   long long me = ms + p.rows_per_split;
   if (me > ((p.Mp + 127) / 128) * 128) me = ((p.Mp + 127) / 128) * 128;
@@ -179,7 +197,10 @@ extern "C" int uh_conv_wgrad(int B, int H, int W, const void* dy, int dy_cstride
   p.N = N;
   p.K = K;
   p.Wp = W + 1;
+  p.S = S;
+  p.remap = (S >= 8) ? 1 : 0;
   dim3 grid(N / 64, K / 64, S);
+  if (p.remap) grid = dim3((unsigned)(8 * ((S + 7) / 8) * (N / 64) * (K / 64)), 1, 1);
   hipStream_t st = (hipStream_t)s;
   if (T == 9) {
     static bool attr = false;
