@@ -225,6 +225,12 @@ int uh_gate8_bwd(long long Mp, const void* dout, int d_cstride, int d_coff, cons
 /* NCHW fp32 image (Cin <= 8) -> 8-channel padded-linear bf16 */
 int uh_nchw_to_c8(int B, int Cin, int H, int W, const float* x, void* out, int o_cstride, int o_coff, uh_stream s);
 
+/* ---- optimizer step: torch.optim.Adam(params, lr) as the reference's trainer builds it (training_utils.py:107),
+ * over ONE flat fp32 buffer (p, g, m, v: n floats each, n a multiple of 4, 16-byte aligned); step counts from 1:
+ *   g' = g + wd*p; m += (1-b1)(g'-m); v = b2 v + (1-b2) g'^2; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps) */
+int uh_adam_step(long long n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2,
+                 float eps, float weight_decay, int step, uh_stream s);
+
 /* ---- clDice soft-skeleton loss, fp32 planes [planes][H][W] (losses/cl_dice.py) ---------------------
  * soft_erode (cl_dice.py:12-17): 5-point-cross minimum, out-of-image neighbours ignored; clamp != 0 first
  * clamps the input to [0,1] (cl_dice.py:116-117).  soft_dilate (cl_dice.py:24-27): 3x3 maximum. */

@@ -45,7 +45,8 @@ def _worker(rank, world, port, out_dir):
         w = b.pop("work", None)
         assert w is not None, "every bucket must have been reduced"
         w.wait()
-    flat = trainer.buckets.flat.clone()
+    flat = trainer.buckets.flat[:trainer.buckets.total].clone()     # the buffer is padded to a multiple of 4 floats
+    assert trainer.buckets.flat[trainer.buckets.total:].abs().sum().item() == 0
     assert all(p.grad.data_ptr() == trainer.buckets.views[n].data_ptr() for n, p in model.named_parameters())
     torch.save({"flat": flat, "idx": idx, "w0": model.conv1_1.weight.detach().clone()},
                os.path.join(out_dir, f"rank{rank}.pt"))

@@ -462,3 +462,24 @@ def test_bad_arguments_are_reported():
              a.ptr, S())
     with pytest.raises(_lib.HipKernelError, match="even"):
         call("uh_maxpool2_fwd", 1, 3, 4, 64, a.ptr, 64, 0, a.ptr, 64, 0, S())
+
+
+def test_adam_step_matches_torch():
+    """uh_adam_step over a flat buffer == torch.optim.Adam (defaults of training_utils.py:107), three steps"""
+    g = torch.Generator().manual_seed(21)
+    n = 4096 * 3 + 8
+    p0 = torch.randn(n, generator=g)
+    grads = [torch.randn(n, generator=g) * s for s in (1.0, 0.1, 3.0)]
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=1e-3)
+    pd, m, v = p0.clone().to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for step, gr in enumerate(grads, start=1):
+        ref.grad = gr.clone()
+        opt.step()
+        gd = gr.to(DEV)
+        call("uh_adam_step", n, pd.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), 1e-3, 0.9, 0.999, 1e-8, 0.0,
+             step, S())
+        torch.cuda.synchronize()
+        torch.testing.assert_close(pd.cpu(), ref.detach(), rtol=1e-6, atol=1e-7)
+    with pytest.raises(_lib.HipKernelError):
+        call("uh_adam_step", n + 1, pd.data_ptr(), pd.data_ptr(), m.data_ptr(), v.data_ptr(), 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, S())

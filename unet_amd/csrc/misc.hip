@@ -1,5 +1,6 @@
 // Error plumbing, geometry helpers, weight packing, row masks, layout shuffles (space<->depth).
 #include <stdarg.h>
+#include <math.h>
 #include <stdio.h>
 #include "common.h"
 
@@ -151,4 +152,43 @@ extern "C" int uh_space_to_depth2(int B, int H, int W, int C, const void* in, in
 extern "C" int uh_depth_to_space2(int B, int H, int W, int C, const void* in, int i_cstride, int i_coff, void* out,
                                   int o_cstride, int o_coff, uh_stream s) {
   return s2d_launch(false, B, H, W, C, in, i_cstride, i_coff, out, o_cstride, o_coff, s);
+}
+
+// ---- Adam over one flat parameter buffer (torch.optim.Adam defaults, trainer/training_utils.py:107) ------------
+// p, g, m, v: n floats each.  One pass: 16 B read + 12 B written per parameter; the 82 parameter tensors of
+// the U-Net are views of one buffer, so this is one launch instead of a multi-tensor sweep.
+__global__ __launch_bounds__(256) void adam_kernel(long long n4, float4* __restrict__ p, const float4* __restrict__ g,
+                                                   float4* __restrict__ m, float4* __restrict__ v, float b1, float b2,
+                                                   float step_size, float inv_sqrt_bc2, float eps, float wd) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    float4 pp = p[i], gg = g[i], mm = m[i], vv = v[i];
+    float* pf = (float*)&pp;
+    float* gf = (float*)&gg;
+    float* mf = (float*)&mm;
+    float* vf = (float*)&vv;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gr = gf[j] + wd * pf[j];
+      mf[j] = mf[j] + (1.f - b1) * (gr - mf[j]);                 // lerp, as torch's fused kernel
+      vf[j] = b2 * vf[j] + (1.f - b2) * gr * gr;
+      const float denom = sqrtf(vf[j]) * inv_sqrt_bc2 + eps;
+      pf[j] -= step_size * (mf[j] / denom);
+    }
+    p[i] = pp;
+    m[i] = mm;
+    v[i] = vv;
+  }
+}
+
+extern "C" int uh_adam_step(long long n, float* p, const float* g, float* m, float* v, float lr, float beta1,
+                            float beta2, float eps, float weight_decay, int step, uh_stream s) {
+  UH_REQUIRE(n > 0 && n % 4 == 0 && p && g && m && v && step >= 1, "adam_step: bad arguments (n must be a multiple of 4)");
+  UH_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam_step: buffers must be 16-byte aligned");
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  const long long n4 = n / 4;
+  long long blocks = (n4 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, n4, (float4*)p, (const float4*)g,
+                     (float4*)m, (float4*)v, beta1, beta2, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), eps, weight_decay);
+  return uh_check_launch("adam_step");
 }

@@ -20,6 +20,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
+from . import _lib
 from .engine import UNetRun
 
 
@@ -72,7 +73,9 @@ class GradBuckets:
         order = backward_param_order(model)
         dev = next(model.parameters()).device
         total = sum(params[n].numel() for n in order)
-        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.total = total
+        self.order = order
+        self.flat = torch.zeros((total + 3) // 4 * 4, dtype=torch.float32, device=dev)   # padded for 16-byte vectors
         self.views, self.bucket_of, self.buckets = {}, {}, []
         off = start = 0
         names = []
@@ -100,6 +103,43 @@ class GradBuckets:
             b["pending"] = set(b["names"])
 
 
+class FlatAdam:
+    """torch.optim.Adam(model.parameters(), lr) (training_utils.py:107) as one kernel launch: the parameters are
+    re-pointed into one flat fp32 buffer laid out like the gradient buckets, so p, g, m, v are four flat arrays."""
+
+    def __init__(self, model, buckets, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.model = model
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.g = buckets.flat
+        self.p = torch.zeros_like(self.g)
+        self.m = torch.zeros_like(self.g)
+        self.v = torch.zeros_like(self.g)
+        self.steps = 0
+        params = dict(model.named_parameters())
+        off = 0
+        with torch.no_grad():
+            for n in buckets.order:
+                q = params[n]
+                view = self.p[off:off + q.numel()].view(q.shape)
+                view.copy_(q.data)
+                q.data = view                      # the module's parameter now lives in the flat buffer
+                off += q.numel()
+
+    def step(self):
+        self.steps += 1
+        _lib.call("uh_adam_step", self.p.numel(), self.p.data_ptr(), self.g.data_ptr(), self.m.data_ptr(),
+                  self.v.data_ptr(), self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.steps,
+                  torch.cuda.current_stream(self.p.device).cuda_stream)
+        # the kernel wrote through raw pointers: autograd's version counters did not move, and the packed bf16
+        # operands key on them
+        pk = getattr(self.model, "_packer", None)
+        if pk is not None:
+            pk.mark_dirty()
+
+    def zero_grad(self, set_to_none=False):
+        pass                                       # every gradient is overwritten by the next backward pass
+
+
 class DataParallelTrainer:
     """fwd + loss + bwd (+ bucketed all-reduce) + Adam for one shard per rank."""
 
@@ -110,7 +150,7 @@ class DataParallelTrainer:
         self.group = process_group
         self.criterion = criterion if criterion is not None else nn.BCEWithLogitsLoss()
         self.buckets = GradBuckets(model, bucket_bytes)
-        self.optimizer = torch.optim.Adam(model.parameters(), lr=lr, fused=True)   # training_utils.py:107
+        self.optimizer = FlatAdam(model, self.buckets, lr=lr)                      # training_utils.py:107
         self.timer = None
         # UNET_AMD_FORCE_COLLECTIVES=1 runs the broadcasts and all-reduces with a single rank too (a rehearsal
         # of the RCCL calls on a one-GPU machine)

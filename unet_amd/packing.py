@@ -60,6 +60,11 @@ class WeightPacker:
         """False once a parameter's storage moved (model.to(), a new tensor assigned)."""
         return all(p.data_ptr() == q for g in self.groups.values() for p, q in zip(g["params"], g["ptrs"]))
 
+    def mark_dirty(self):
+        """weights were changed by something that does not move Tensor._version (a kernel writing raw pointers)"""
+        for g in self.groups.values():
+            g["versions"] = None
+
     def get(self, direction, stream):
         """{layer name: packed bf16 operand}, repacked first if any weight changed since the last repack."""
         g = self.groups[direction]
