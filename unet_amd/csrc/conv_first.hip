@@ -1,10 +1,35 @@
 // First layer: Conv2d(Cin <= 4 -> 64, 3x3, pad 1) straight from the caller's NCHW fp32 image.
-// K = 9*Cin <= 36 is too shallow for the matrix cores to pay, and the layer is bound by writing
-// its 64-channel output, so it runs on the vector ALUs in fp32: a wave covers 64 consecutive
-// padded-linear positions, each of the four waves of a workgroup produces 16 of the 64 output
-// channels (weights are wave-uniform, i.e. scalar loads), and the NCHW->NHWC/bf16 layout change
-// is fused into the store.  Batch-norm statistics come from the fp32 results.
+//
+// K = 9*Cin <= 36 is one or two MFMA k-blocks, and the layer is bound by writing its 64-channel output, so the
+// point is only to keep arithmetic out of the way: on the vector ALUs the 1728 FMAs per pixel took 3.5x the
+// time of the store.  The matrix cores take bf16, the layer's contract is fp32 (the input image and these
+// weights are not rounded anywhere else in the network), so both operands are split x = hi + lo into two bf16
+// values and the product is hi*hi + hi*lo + lo*hi with fp32 accumulation: relative error ~2^-16 per product,
+// below the fp16 rounding of the stored result.
+//   forward : D[channel][pixel] = W[channel][k] * X^T[k][pixel]; weight rows are permuted so that the four
+//             channel tiles a lane holds for its pixel are 16 ADJACENT channels (two 16-byte stores); the
+//             im2col fragment of a pixel is gathered straight from NCHW with bounds checks; BatchNorm partial
+//             sums come from the fp32 accumulators.
+//   wgrad   : D[channel][tap] = sum over pixels dY^T * im2col(X), 32 pixels per MFMA, dY is bf16 already.
 #include "common.h"
+
+__device__ __forceinline__ void split_bf16(float v, bf16& hi, bf16& lo) {
+  hi = (bf16)v;
+  lo = (bf16)(v - (float)hi);
+}
+
+// x[b][ci][y+ky-1][x+kx-1] for tap k = ci*9 + ky*3 + kx of pixel (b,y,x); 0 outside the image / beyond KK taps
+template <int CIN>
+__device__ __forceinline__ float first_tap(const float* __restrict__ x, int H, int W, long long b, int py, int px, int k,
+                                           bool pixel_ok) {
+  const int ci = (k * 57) >> 9;            // k / 9 for k < 64
+  const int r = k - ci * 9;
+  const int ky = (r * 11) >> 5;            // r / 3 for r < 9
+  const int kx = r - ky * 3;
+  const int yy = py + ky - 1, xx = px + kx - 1;
+  const bool ok = pixel_ok && k < CIN * 9 && yy >= 0 && yy < H && xx >= 0 && xx < W;
+  return ok ? x[((b * CIN + ci) * H + yy) * W + xx] : 0.f;
+}
 
 template <int CIN>
 __global__ __launch_bounds__(256) void conv_first_fwd_kernel(int B, int H, int W, const float* __restrict__ x,
@@ -14,79 +39,124 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(int B, int H, int W
                                                              const float* __restrict__ shift, char* __restrict__ out,
                                                              int o_cs, int o_co, float* __restrict__ stat_partial) {
   constexpr int KK = CIN * 9;
-  const int lane = threadIdx.x & 63;
-  const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 16-channel quarter
+  constexpr int NKB = (KK + 31) / 32;
+  __shared__ float red[4][2][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
   const int Wp = W + 1, Hp = H + 1;
   const long long Mp = (long long)B * Hp * Wp;
-  const long long mblk = (long long)blockIdx.x * 512;
+  const long long mwave = (long long)blockIdx.x * 512 + wave * 128;
+
+  // weight fragments (A operand): tile j, row r = l15 is output channel (r/4)*16 + j*4 + r%4
+  bf16x8 whi[NKB][4], wlo[NKB][4];
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = (l15 >> 2) * 16 + j * 4 + (l15 & 3);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int k = kb * 32 + g * 8 + t;
+        const float v = (k < KK) ? w[c * KK + k] : 0.f;
+        bf16 h, l;
+        split_bf16(v, h, l);
+        whi[kb][j][t] = h;
+        wlo[kb][j][t] = l;
+      }
+    }
+  // this lane's 16 output channels: g*16 + q
+  float cb[16], csc[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    if (mode == UH_EPI_AFFINE_RELU) {
+      csc[q] = scale[g * 16 + q];
+      cb[q] = shift[g * 16 + q];       // folded inference BN: shift already contains the conv bias
+    } else {
+      csc[q] = 1.f;
+      cb[q] = bias ? bias[g * 16 + q] : 0.f;
+    }
+  }
   float s1[16], s2[16];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) s1[j] = s2[j] = 0.f;
+  for (int q = 0; q < 16; ++q) s1[q] = s2[q] = 0.f;
 
-  for (int it = 0; it < 8; ++it) {
-    const long long m = mblk + it * 64 + lane;
-    if (m >= Mp) continue;
+  for (int tile = 0; tile < 8; ++tile) {
+    const long long m = mwave + tile * 16 + l15;
     const int px = (int)(m % Wp);
     const long long r = m / Wp;
     const int py = (int)(r % Hp);
     const long long b = r / Hp;
-    const bool interior = (px < W && py < H);
-    float in[KK];
+    const bool interior = (m < Mp && px < W && py < H);
+    bf16x8 xhi[NKB], xlo[NKB];
 #pragma unroll
-    for (int ci = 0; ci < CIN; ++ci)
+    for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int yy = py + ky - 1, xx = px + kx - 1;
-          const bool ok = interior && yy >= 0 && yy < H && xx >= 0 && xx < W;
-          in[ci * 9 + ky * 3 + kx] = ok ? x[((b * CIN + ci) * H + yy) * W + xx] : 0.f;
-        }
-    float acc[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = (bias && mode != UH_EPI_AFFINE_RELU) ? bias[q * 16 + j] : 0.f;
-#pragma unroll
-    for (int k = 0; k < KK; ++k)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) acc[j] += in[k] * w[(q * 16 + j) * KK + k];
-    if (mode == UH_EPI_AFFINE_RELU) {
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        // folded inference BN: shift already contains the conv bias
-        acc[j] = interior ? fmaxf(acc[j] * scale[q * 16 + j] + shift[q * 16 + j], 0.f) : 0.f;
+      for (int t = 0; t < 8; ++t) {
+        const float v = first_tap<CIN>(x, H, W, b, py, px, kb * 32 + g * 8 + t, interior);
+        bf16 h, l;
+        split_bf16(v, h, l);
+        xhi[kb][t] = h;
+        xlo[kb][t] = l;
       }
-    } else {
+    float v[16];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        acc[j] = interior ? acc[j] : 0.f;
-        s1[j] += acc[j];
-        s2[j] += acc[j] * acc[j];
+    for (int j = 0; j < 4; ++j) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo[kb][j], xhi[kb], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[kb][j], xlo[kb], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[kb][j], xhi[kb], acc, 0, 0, 0);
       }
-    }
-    float lo[8], hi[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      lo[j] = acc[j];
-      hi[j] = acc[8 + j];
+      for (int e = 0; e < 4; ++e) v[j * 4 + e] = acc[e];       // channel g*16 + j*4 + e of pixel l15
     }
-    char* dst = out + (m * o_cs + o_co + q * 16) * 2;
-    if (mode == UH_EPI_RAW_STATS) {   // BatchNorm input: fp16
-      *(U4*)dst = pack8h(lo);
-      *(U4*)(dst + 16) = pack8h(hi);
-    } else {
-      *(U4*)dst = pack8(lo);
-      *(U4*)(dst + 16) = pack8(hi);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      float t = v[q];
+      if (mode == UH_EPI_AFFINE_RELU) t = fmaxf(t * csc[q] + cb[q], 0.f);
+      else t += cb[q];
+      t = interior ? t : 0.f;
+      s1[q] += t;
+      s2[q] += t * t;
+      v[q] = t;
+    }
+    if (m < Mp) {
+      float lo8[8], hi8[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { lo8[q] = v[q]; hi8[q] = v[8 + q]; }
+      char* dst = out + (m * o_cs + o_co + g * 16) * 2;
+      if (mode == UH_EPI_RAW_STATS) {   // BatchNorm input: fp16
+        *(U4*)dst = pack8h(lo8);
+        *(U4*)(dst + 16) = pack8h(hi8);
+      } else {
+        *(U4*)dst = pack8(lo8);
+        *(U4*)(dst + 16) = pack8(hi8);
+      }
     }
   }
   if (mode == UH_EPI_RAW_STATS) {
+    // sum over the 16 pixels (lanes l15) of every group g, then over the four waves
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const float a = wave_sum(s1[j]);
-      const float c = wave_sum(s2[j]);
-      if (lane == 0) {
-        stat_partial[((long long)blockIdx.x * 2 + 0) * 64 + q * 16 + j] = a;
-        stat_partial[((long long)blockIdx.x * 2 + 1) * 64 + q * 16 + j] = c;
+    for (int q = 0; q < 16; ++q) {
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        s1[q] += __shfl_xor(s1[q], o, 64);
+        s2[q] += __shfl_xor(s2[q], o, 64);
       }
+    }
+    if (l15 == 0) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        red[wave][0][g * 16 + q] = s1[q];
+        red[wave][1][g * 16 + q] = s2[q];
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      const int which = threadIdx.x >> 6, c = threadIdx.x & 63;
+      stat_partial[((long long)blockIdx.x * 2 + which) * 64 + c] =
+          (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
     }
   }
 }
@@ -118,65 +188,99 @@ extern "C" int uh_conv_first_fwd(int B, int H, int W, int Cin, int Cout, const f
   return uh_check_launch("conv_first_fwd");
 }
 
-// ---- weight gradient: dW[co][ci][ky][kx] = sum_pixels dy[m][co] * x[b][ci][y+ky-1][x+kx-1] ---------------
-// lane = output channel; a workgroup walks 16 image rows of a 64-pixel-wide strip; per row the
-// three input rows it touches are staged in LDS (fp32, zero padded) and read back as broadcasts.
+// ---- weight gradient: dW[co][k] = sum_pixels dy[m][co] * im2col(x)[m][k] ------------------------------------
+// A wave takes 32 padded-linear positions per step: A fragments are dY^T (row = channel, 8 consecutive pixels per
+// lane, bf16 as stored), B fragments the im2col taps of the same pixels split into hi + lo.  dY is zero on pad
+// rows, so whatever finite value the gather returns there does not matter (it returns 0).
 template <int CIN>
 __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(int B, int H, int W, const float* __restrict__ x,
                                                                const char* __restrict__ dy, int dy_cs, int dy_co,
                                                                float* __restrict__ partial) {
   constexpr int KK = CIN * 9;
-  __shared__ float xs[CIN * 3 * 66];
-  __shared__ float red[4 * 64 * KK];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 16;
-  const long long b = blockIdx.z;
+  constexpr int NT = ((KK + 31) / 32) * 2;        // 16-tap tiles
+  __shared__ float red[64][NT * 16 + 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
   const int Wp = W + 1, Hp = H + 1;
-  float acc[KK];
+  const long long Mp = (long long)B * Hp * Wp;
+  const long long nblk = (Mp + 31) / 32;
+  f32x4 acc[4][NT];
 #pragma unroll
-  for (int k = 0; k < KK; ++k) acc[k] = 0.f;
-  for (int ry = 0; ry < 16; ++ry) {
-    const int y = y0 + ry;
-    if (y >= H) break;
-    __syncthreads();
-    for (int i = tid; i < CIN * 3 * 66; i += 256) {
-      const int xx = x0 + (i % 66) - 1;
-      const int ky = (i / 66) % 3;
-      const int ci = i / (66 * 3);
-      const int yy = y + ky - 1;
-      xs[i] = (xx >= 0 && xx < W && yy >= 0 && yy < H) ? x[((b * CIN + ci) * H + yy) * W + xx] : 0.f;
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) acc[j][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (long long pb = (long long)blockIdx.x * 4 + wave; pb < nblk; pb += (long long)gridDim.x * 4) {
+    const long long m0 = pb * 32 + g * 8;              // this lane's 8 consecutive positions
+    // dY^T fragments
+    bf16x8 af[4];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const long long m = m0 + t;
+      const bool ok = m < Mp;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        af[j][t] = ok ? *(const bf16*)(dy + (m * dy_cs + dy_co + j * 16 + l15) * 2) : (bf16)0.f;
     }
-    __syncthreads();
-    for (int p = 0; p < 16; ++p) {
-      const int px = wave * 16 + p;
-      if (x0 + px >= W) break;
-      const long long m = (b * Hp + y) * Wp + x0 + px;
-      const float d = bf2f(*(const bf16*)(dy + (m * dy_cs + dy_co + lane) * 2));
+    // positions of the 8 pixels
+    int px = (int)(m0 % Wp);
+    long long r = m0 / Wp;
+    int py = (int)(r % Hp);
+    long long b = r / Hp;
+    bf16x8 xhi[NT], xlo[NT];
 #pragma unroll
-      for (int ci = 0; ci < CIN; ++ci)
+    for (int t = 0; t < 8; ++t) {
+      const bool ok = (m0 + t < Mp) && px < W && py < H;
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-          for (int kx = 0; kx < 3; ++kx) acc[ci * 9 + ky * 3 + kx] += d * xs[(ci * 3 + ky) * 66 + px + kx];
+      for (int tt = 0; tt < NT; ++tt) {
+        const float v = first_tap<CIN>(x, H, W, b, py, px, tt * 16 + l15, ok);
+        bf16 h, l;
+        split_bf16(v, h, l);
+        xhi[tt][t] = h;
+        xlo[tt][t] = l;
+      }
+      if (++px == Wp) {
+        px = 0;
+        if (++py == Hp) { py = 0; ++b; }
+      }
     }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) {
+        acc[j][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j], xlo[tt], acc[j][tt], 0, 0, 0);
+        acc[j][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j], xhi[tt], acc[j][tt], 0, 0, 0);
+      }
   }
+  // D[j][tt]: rows = channel j*16 + g*4 + e, column = tap tt*16 + l15; the four waves add in turn
+  for (int wv = 0; wv < 4; ++wv) {
+    if (wave == wv) {
 #pragma unroll
-  for (int k = 0; k < KK; ++k) red[(wave * 64 + lane) * KK + k] = acc[k];
-  __syncthreads();
-  const long long blk = ((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-  for (int i = tid; i < 64 * KK; i += 256)
-    partial[blk * 64 * KK + i] = red[i] + red[64 * KK + i] + red[2 * 64 * KK + i] + red[3 * 64 * KK + i];
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float* d = &red[j * 16 + g * 4 + e][tt * 16 + l15];
+            *d = (wv == 0) ? acc[j][tt][e] : *d + acc[j][tt][e];
+          }
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < 64 * KK; i += 256) partial[(long long)blockIdx.x * 64 * KK + i] = red[i / KK][i % KK];
 }
 
-extern "C" int uh_conv_first_wgrad_parts(int B, int H, int W) { return uh_cdiv(W, 64) * uh_cdiv(H, 16) * B; }
+extern "C" int uh_conv_first_wgrad_parts(int B, int H, int W) {
+  const long long blocks = (uh_mp(B, H, W) + 127) / 128;          // 4 waves x 32 positions per step
+  return (int)(blocks < 1024 ? blocks : 1024);
+}
 
 extern "C" int uh_conv_first_wgrad(int B, int H, int W, int Cin, int Cout, const float* x, const void* dy,
                                    int dy_cstride, int dy_coff, float* partial, uh_stream s) {
   UH_REQUIRE(B > 0 && H > 0 && W > 0 && x && dy && partial, "conv_first_wgrad: bad arguments");
   UH_REQUIRE(Cin >= 1 && Cin <= 4, "conv_first_wgrad: Cin=%d must be 1..4", Cin);
   UH_REQUIRE(Cout == 64, "conv_first_wgrad: Cout=%d (only 64 is built)", Cout);
-  const dim3 grid(uh_cdiv(W, 64), uh_cdiv(H, 16), B);
+  const dim3 grid((unsigned)uh_conv_first_wgrad_parts(B, H, W));
   hipStream_t st = (hipStream_t)s;
 #define LAUNCH(CI)                                                                                              \
   hipLaunchKernelGGL((conv_first_wgrad_kernel<CI>), grid, dim3(256), 0, st, B, H, W, x, (const char*)dy, dy_cstride, \
