@@ -70,14 +70,43 @@ extern "C" int uh_pack_weights(const float* src, void* dst, int N, int T, int K,
 }
 
 // Many repacks in one launch: blockIdx.y selects the descriptor (device memory), blockIdx.x strides over its
-// elements.  A training step repacks every MFMA weight operand of the network twice (forward and rotated for
-// the input gradient); one launch per direction replaces ~20 launches of a few microseconds each.
-__global__ void pack_multi_kernel(const uh_pack_desc* __restrict__ descs) {
-  const uh_pack_desc d = descs[blockIdx.y];  // dst field: dst_bf16
+// work.  A training step repacks every MFMA weight operand of the network twice (forward and rotated for the
+// input gradient); one launch per direction replaces ~20 launches.
+// The repack is a transpose: in the source the taps of one (n, k) pair are contiguous, in the destination k is.
+// Tensors with N and K multiples of 32 go through 32 x 32 x T tiles in LDS, read in source order (runs of 32*T
+// floats) and written in destination order (runs of 32 bf16); anything else takes the element-wise loop.
+__global__ __launch_bounds__(256) void pack_multi_kernel(const uh_pack_desc* __restrict__ descs) {
+  __shared__ float tile[32 * 9 * 33];
+  const uh_pack_desc d = descs[blockIdx.y];
   const int N = (int)d.N, T = (int)d.T, K = (int)d.K;
-  const long long total = (long long)N * T * K;
   const float* __restrict__ src = d.src;
   bf16* __restrict__ dst = (bf16*)d.dst_bf16;
+  if (d.st == 1 && T <= 9 && N % 32 == 0 && K % 32 == 0) {
+    const int tk = K / 32, ntiles = (N / 32) * tk;
+    const bool k_fast = d.sk < d.sn;               // which of n, k is the faster-varying source dimension
+    const int per = 32 * T * 32;
+    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+      const int n0 = (tl / tk) * 32, k0 = (tl % tk) * 32;
+      __syncthreads();
+      for (int i = threadIdx.x; i < per; i += 256) {
+        const int ts = i % T;
+        const int r = i / T;
+        const int a = r & 31, bq = r >> 5;         // a: faster source dimension
+        const int nn = k_fast ? bq : a, kk = k_fast ? a : bq;
+        const int t = d.reverse ? (T - 1 - ts) : ts;
+        tile[(nn * T + t) * 33 + kk] = src[(n0 + nn) * d.sn + ts + (k0 + kk) * d.sk];
+      }
+      __syncthreads();
+      for (int j = threadIdx.x; j < per; j += 256) {
+        const int kk = j & 31;
+        const int r = j >> 5;                      // nn * T + t
+        const int t = r % T, nn = r / T;
+        dst[(n0 + nn) * d.on + t * d.ot + k0 + kk] = f2bf(tile[r * 33 + kk]);
+      }
+    }
+    return;
+  }
+  const long long total = (long long)N * T * K;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int k = (int)(i % K);
     const long long r = i / K;

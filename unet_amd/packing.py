@@ -70,7 +70,7 @@ class WeightPacker:
         g = self.groups[direction]
         versions = [p._version for p in g["params"]]
         if versions != g["versions"]:
-            _lib.call("uh_pack_weights_multi", g["desc"].data_ptr(), len(g["params"]), 128, stream)
+            _lib.call("uh_pack_weights_multi", g["desc"].data_ptr(), len(g["params"]), 256, stream)
             g["versions"] = versions
         return g["views"]
 
