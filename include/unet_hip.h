@@ -231,6 +231,15 @@ int uh_nchw_to_c8(int B, int Cin, int H, int W, const float* x, void* out, int o
 int uh_adam_step(long long n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2,
                  float eps, float weight_decay, int step, uh_stream s);
 
+/* ---- evaluation: binarised predictions and confusion counts, fp32 logits and masks [planes][n] ---------
+ * pred = sigmoid(logit) > 0.5 evaluated in fp32 (trainer/k_fold.py:289-290; test_helper/utils.py:130-131), so
+ * logit 0 and NaN are background; counted against mask == 1 / mask == 0 exactly (k_fold.py:371-380: other
+ * mask values fall into no class).  counts[plane][4] = tp, tn, fp, fn are ADDED to (the caller zeroes them
+ * once and may keep accumulating over batches: one plane = k_fold.py::evaluate_model's whole-set counts,
+ * one plane per image = test_helper/utils.py::save_results' per-sample counts). */
+int uh_confusion_counts(int planes, long long n, const float* logits, const float* mask, long long* counts,
+                        uh_stream s);
+
 /* ---- clDice soft-skeleton loss, fp32 planes [planes][H][W] (losses/cl_dice.py) ---------------------
  * soft_erode (cl_dice.py:12-17): 5-point-cross minimum, out-of-image neighbours ignored; clamp != 0 first
  * clamps the input to [0,1] (cl_dice.py:116-117).  soft_dilate (cl_dice.py:24-27): 3x3 maximum. */

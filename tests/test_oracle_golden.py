@@ -146,3 +146,22 @@ def test_autograd_tie_rules(golden_dir):
     np.testing.assert_array_equal(fx["min_a"], [0.5, 1.0, 0.0])     # min: ties split 1/2, 1/2
     np.testing.assert_array_equal(fx["relu"], [0.0, 0.0, 1.0])      # relu'(0) = 0
     np.testing.assert_array_equal(fx["clamp"], [0.0, 1.0, 1.0, 1.0, 0.0])  # clamp passes grad at the bounds
+
+
+def test_metrics_oracle_matches_reference(golden_dir):
+    """oracle/metrics.py against the outputs of the reference's evaluation helpers (metrics_cases.npz)."""
+    from oracle import metrics as om
+    fx = _load(golden_dir, "metrics_cases.npz")
+    fold_keys, sample_keys = list(fx["fold_keys"]), list(fx["sample_keys"])
+    cases = sorted(k[:-len(".logits")] for k in fx.files if k.endswith(".logits"))
+    assert len(cases) == 6
+    for c in cases:
+        logits, mask = fx[c + ".logits"], fx[c + ".mask"]
+        pred = om.binarise(logits)
+        np.testing.assert_array_equal(pred, fx[c + ".pred"], err_msg=c)
+        y_true = np.transpose(mask, (0, 2, 3, 1)).squeeze()            # masks arrive as [N,H,W,1] arrays
+        got = om.fold_metrics(y_true, pred.squeeze())
+        np.testing.assert_array_equal([got[k] for k in fold_keys], fx[c + ".fold"], err_msg=c)
+        for j in range(len(logits)):
+            sm = om.sample_metrics(pred[j], mask[j])
+            np.testing.assert_array_equal([sm[k] for k in sample_keys], fx[c + ".sample"][j], err_msg=f"{c}[{j}]")

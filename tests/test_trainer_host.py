@@ -1,0 +1,84 @@
+"""Host-side logic of unet_amd/trainer.py (no device work): the plateau scheduler against torch's own
+ReduceLROnPlateau, the early-stopping loop against the oracle's restatement of training_utils.py:227-242, and the
+metric formulas against the fixture captured from the reference's helpers.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import metrics as om
+
+trainer = pytest.importorskip("unet_amd.trainer", reason="libunet_hip.so not built")
+
+
+SEQUENCES = {
+    "improving": [1.0 / (k + 1) for k in range(20)],
+    "flat": [0.5] * 30,
+    "plateau_then_drop": [0.9, 0.8] + [0.8] * 8 + [0.4] + [0.41] * 14,
+    "tiny_gains": [0.5 * (1 - 5e-5) ** k for k in range(25)],       # below the 1e-4 relative threshold
+    "noisy": list(0.6 + 0.3 * np.cos(np.arange(40) * 1.3) * np.exp(-np.arange(40) / 15)),
+    "nan": [0.7, 0.6, float("nan")] + [0.65] * 10,
+}
+
+
+@pytest.mark.parametrize("name", sorted(SEQUENCES))
+def test_plateau_lr_follows_torch(name):
+    seq = SEQUENCES[name]
+    state = {"lr": 1e-3}
+    sched = trainer.PlateauLR(lambda: state["lr"], lambda v: state.__setitem__("lr", v), patience=5, factor=0.5)
+    got = []
+    for v in seq:
+        sched.step(v)
+        got.append(state["lr"])
+    assert got == om.plateau_lrs(seq, lr=1e-3, patience=5, factor=0.5)
+
+
+def test_plateau_lr_stops_at_eps():
+    state = {"lr": 3e-8}
+    sched = trainer.PlateauLR(lambda: state["lr"], lambda v: state.__setitem__("lr", v), patience=0, factor=0.5)
+    seq = [1.0] * 6
+    got = []
+    for v in seq:
+        sched.step(v)
+        got.append(state["lr"])
+    assert got == om.plateau_lrs(seq, lr=3e-8, patience=0, factor=0.5)
+
+
+@pytest.mark.parametrize("name", sorted(SEQUENCES))
+@pytest.mark.parametrize("patience", [1, 3, 10])
+def test_fit_loop_early_stopping(name, patience):
+    seq = SEQUENCES[name]
+    saved, lrs = [], {"lr": 1e-3}
+    epoch_box = {}
+
+    def train_epoch(epoch):
+        epoch_box["e"] = epoch
+        return 1.0
+
+    sched = trainer.PlateauLR(lambda: lrs["lr"], lambda v: lrs.__setitem__("lr", v))
+    tr, va, best = trainer.fit_loop(len(seq), patience, train_epoch, lambda e: seq[e], sched,
+                                    lambda: saved.append(epoch_box["e"]), log=lambda *_: None)
+    n_run, want_saved = om.early_stop_epochs(seq, patience)
+    assert len(va) == n_run and len(tr) == n_run
+    assert saved == want_saved
+    finite = [v for v in seq[:n_run] if v == v]
+    assert best == min(finite)
+
+
+def test_metric_formulas_match_reference_fixture(golden_dir):
+    fx = np.load(os.path.join(golden_dir, "metrics_cases.npz"), allow_pickle=False)
+    fold_keys, sample_keys = list(fx["fold_keys"]), list(fx["sample_keys"])
+    for c in sorted(k[:-len(".logits")] for k in fx.files if k.endswith(".logits")):
+        mask, pred = fx[c + ".mask"], fx[c + ".pred"]
+        y_true = np.transpose(mask, (0, 2, 3, 1))
+        got = trainer.calculate_metrics(y_true, pred)
+        np.testing.assert_array_equal([got[k] for k in fold_keys], fx[c + ".fold"], err_msg=c)
+        tp, tn, fp, fn = om.confusion_counts(y_true.squeeze(), pred.squeeze())
+        got = trainer.metrics_from_counts(tp, tn, fp, fn)
+        np.testing.assert_array_equal([got[k] for k in fold_keys], fx[c + ".fold"], err_msg=c)
+        if c == "mask_not_binary":
+            continue        # the per-sample report multiplies by the mask instead of comparing with it
+        counts = [om.confusion_counts(mask[j], pred[j]) for j in range(len(mask))]
+        per = trainer.sample_metrics_from_counts(counts)
+        for i, k in enumerate(sample_keys):
+            np.testing.assert_array_equal(per[k], fx[c + ".sample"][:, i], err_msg=f"{c}.{k}")

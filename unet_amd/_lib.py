@@ -68,6 +68,7 @@ SIGNATURES = {
     "uh_gate8_bwd": (I, [L, P, I, I, P, I, I, P, I, I, P, P, I, I, P, I, I, P, P]),
     "uh_nchw_to_c8": (I, [I, I, I, I, P, P, I, I, P]),
     "uh_adam_step": (I, [L, P, P, P, P, F, F, F, F, F, I, P]),
+    "uh_confusion_counts": (I, [I, L, P, P, P, P]),
     "uh_soft_erode": (I, [I, I, I, P, P, I, P]),
     "uh_soft_dilate": (I, [I, I, I, P, P, P]),
     "uh_soft_skel_workspace": (Z, [I, I, I]),
