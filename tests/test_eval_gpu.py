@@ -188,3 +188,21 @@ def test_train_model_lunext_cldice_runs_and_early_stops(tmp_path):
     ref.load_state_dict(torch.load(str(ckpt), map_location="cpu", weights_only=True))
     with pytest.raises(NotImplementedError):
         trainer.train_model(tr, va, custom_loss="self_reg", device=DEV)
+
+
+def test_train_kfold_single_process(tmp_path):
+    """Every fold on one GPU (world 1): 2 x 2 short trainings; table, best checkpoint and test metrics come back."""
+    from unet_amd import kfold
+    images, masks = _toy_data(24, 32, seed=8)
+    test = _toy_data(6, 32, seed=9)
+    torch.manual_seed(0)
+    rec, path, best = kfold.train_kfold(images, masks, test_data=test, model_type="UNet", k_fold=2, times=2, epochs=3,
+                                        batch_size=6, eval_batch_size=4, results_file=str(tmp_path / "r.csv"),
+                                        best_model_path=str(tmp_path / "best.pth"), device=DEV, log=lambda *_: None)
+    assert [(r["Time"], r["Fold"]) for r in rec] == [(1, 1), (1, 2), (2, 1), (2, 2)]
+    assert all(0.0 <= r["Dice"] <= 1.0 and r["Training Time"] > 0 for r in rec)
+    assert os.path.exists(path) and (tmp_path / "r.csv").exists()
+    assert sorted(os.listdir(tmp_path)) == ["best.pth", "r.csv"]              # per-fold checkpoints are removed
+    if max(r["Dice"] for r in rec) > 0:
+        assert set(best) == {"dice", "iou", "precision", "recall", "accuracy", "f1"}
+        ref_cpu.RefUNet(3, 1).load_state_dict(torch.load(path, map_location="cpu", weights_only=True))

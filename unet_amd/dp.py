@@ -143,10 +143,13 @@ class FlatAdam:
 class DataParallelTrainer:
     """fwd + loss + bwd (+ bucketed all-reduce) + Adam for one shard per rank."""
 
-    def __init__(self, model, lr=1e-3, criterion=None, bucket_bytes=25 << 20, process_group=None):
+    def __init__(self, model, lr=1e-3, criterion=None, bucket_bytes=25 << 20, process_group=None, standalone=False):
+        """standalone: train alone even inside an initialised process group (independent replicas, e.g. one
+        cross-validation fold per GPU)."""
         self.model = model
-        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        joined = dist.is_initialized() and not standalone
+        self.world = dist.get_world_size(process_group) if joined else 1
+        self.rank = dist.get_rank(process_group) if joined else 0
         self.group = process_group
         self.criterion = criterion if criterion is not None else nn.BCEWithLogitsLoss()
         self.buckets = GradBuckets(model, bucket_bytes)
@@ -154,7 +157,7 @@ class DataParallelTrainer:
         self.timer = None
         # UNET_AMD_FORCE_COLLECTIVES=1 runs the broadcasts and all-reduces with a single rank too (a rehearsal
         # of the RCCL calls on a one-GPU machine)
-        self.collectives = dist.is_initialized() and (self.world > 1 or os.environ.get("UNET_AMD_FORCE_COLLECTIVES") == "1")
+        self.collectives = joined and (self.world > 1 or os.environ.get("UNET_AMD_FORCE_COLLECTIVES") == "1")
         if self.collectives:
             # same initial weights on every rank
             for p in model.parameters():

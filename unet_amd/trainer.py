@@ -178,9 +178,11 @@ def _make_loss(custom_loss):
 
 
 def train_model(train_data, validation_data, model_type="UNet", epochs=50, batch_size=16, learning_rate=0.001,
-                patience=10, device=None, custom_loss=None, model_save_path=None, shuffle_seed=0, log=print):
+                patience=10, device=None, custom_loss=None, model_save_path=None, shuffle_seed=0, log=print,
+                data_parallel=True):
     """trainer/training_utils.py:11.  Same arguments (plus where to keep the best checkpoint, the shuffle seed
-    and a log sink); returns the model with the best-validation weights loaded, in eval mode."""
+    and a log sink); returns the model with the best-validation weights loaded, in eval mode.  Inside an
+    initialised process group a U-Net trains data-parallel over its ranks unless data_parallel=False."""
     from .dp import DataParallelTrainer
     dev = _device(device)
     torch.cuda.set_device(dev)
@@ -199,7 +201,7 @@ def train_model(train_data, validation_data, model_type="UNet", epochs=50, batch
     loss_fn = _make_loss(custom_loss)
 
     if model_type == "UNet":
-        stepper = DataParallelTrainer(model, lr=learning_rate, criterion=loss_fn)
+        stepper = DataParallelTrainer(model, lr=learning_rate, criterion=loss_fn, standalone=not data_parallel)
         opt = stepper.optimizer
         get_lr = lambda: opt.lr                                              # noqa: E731
         set_lr = lambda v: setattr(opt, "lr", v)                             # noqa: E731
