@@ -66,6 +66,8 @@ CONV_SHAPES = [  # B, H, W, Cin, Cout
     (3, 4, 4, 64, 192),        # N not a multiple of 128, tiny image (tiles span several images)
     (1, 32, 32, 192, 128),     # three K chunks
     (2, 2, 2, 128, 256),       # deepest-level shape of a 32x32 input
+    (2, 24, 24, 128, 256),     # 256-wide tiles, several M tiles
+    (1, 16, 16, 64, 512),      # two N tiles of 256
 ]
 
 
@@ -120,7 +122,7 @@ def test_conv_gemm_raw_stats(B, H, W, Cin, Cout):
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 32, 32, 64, 128), (1, 16, 16, 128, 64), (2, 48, 48, 64, 256),
-                                            (1, 16, 16, 64, 64)])
+                                            (1, 16, 16, 64, 64), (3, 40, 40, 128, 256), (2, 16, 16, 192, 512)])
 def test_conv_gemm_even_cuts(B, H, W, Cin, Cout):
     """uh_conv_gemm_ws: workgroups that own pieces of tiles + the fix-up launch give the whole-tile result."""
     g = torch.Generator().manual_seed(B * 77 + H + Cin)
