@@ -205,6 +205,8 @@ def main():
         g = ks["conv_band"]
         achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12            # TFLOP/s over all conv_band_kernel launches
         scale = (args.size / IMG) ** 2
+        config_name = {(IMG, BATCH_PER_GPU): "BASELINE configs[1]", (512, 16): "BASELINE configs[3]"}.get(
+            (args.size, args.batch), "not a BASELINE configuration")
         # HBM-side bytes per launch of the dominant kernel: measured separately with rocprofv3 PMC passes (the
         # profiler cannot run inside this process); only valid for the default workload size
         traffic = None
@@ -218,7 +220,7 @@ def main():
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"UNet 3x{args.size}x{args.size}, batch {args.batch}/GPU, BCEWithLogits, "
-                                   "fwd+bwd+grad all-reduce+Adam (BASELINE configs[1])",
+                                   "fwd+bwd+grad all-reduce+Adam (" + config_name + ")",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}",
                        "loss_last_step": round(loss.item(), 6)},
             "step_mfma_frac": round(value / world * FLOP_PER_IMG_FWD_BWD * scale / PEAK_BF16_DENSE, 4),

@@ -188,3 +188,36 @@ def test_soft_skeleton_order_relations_at_full_size():
     bad = crit(mask, (1 - mask).clamp(1e-6, 1 - 1e-6)).item()
     assert 0 <= good < 0.05 and bad > 0.9, (good, bad)
     assert n == p.numel()
+
+
+@pytest.mark.parametrize("b,hw", [(2, 512), (1, 1024)])
+def test_unet_large_images(b, hw):
+    """BASELINE configs[3] and [4] image sizes (512^2 training, 1024^2 training + batch-1 inference), small batches:
+    a training step is deterministic and finite, and eval-mode inference of one image does not depend on the batch
+    it arrives in (to rounding)."""
+    torch.manual_seed(3)
+    model = unet_amd.UNet(3, 1).to(DEV).train()
+    g = torch.Generator().manual_seed(hw)
+    x = torch.rand(b, 3, hw, hw, generator=g).to(DEV)
+    m = (torch.rand(b, 1, hw, hw, generator=g) > 0.5).float().to(DEV)
+    bce = nn.BCEWithLogitsLoss()
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    l1, g1 = one_step(model, x, m, bce)
+    model.load_state_dict(state)
+    l2, g2 = one_step(model, x, m, bce)
+    assert l1.shape == (b, 1, hw, hw) and torch.isfinite(l1).all()
+    assert torch.equal(l1, l2)
+    for n in g1:
+        assert torch.isfinite(g1[n]).all(), n
+        assert torch.equal(g1[n], g2[n]), n
+    model.eval()
+    with torch.no_grad():
+        full = model(x)
+        single = model(x[:1])
+    scale = full.abs().max().item()
+    assert (full[:1] - single).abs().max().item() <= 1e-2 * scale
+    # the evaluation driver at this size: counts add up to the number of pixels
+    from unet_amd import trainer
+    counts = torch.zeros(4, dtype=torch.int64, device=DEV)
+    trainer.confusion_counts(full, m, counts)
+    assert counts.sum().item() == b * hw * hw
