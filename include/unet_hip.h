@@ -178,7 +178,8 @@ int uh_head_bwd(int B, int H, int W, int C, int OC, const void* a, int a_cstride
 
 /* ---- LUNeXt blocks (models/lunext.py), padded-linear NHWC bf16 with C a multiple of 8 ----------------
  * The 3-channel full-resolution level is carried zero-padded to 8 channels. */
-int uh_dw_parts(long long Mp, int C);
+/* workgroups (= rows of `partial`) of the depthwise forward and weight-gradient kernels */
+int uh_dw_parts(int B, int H, int W, int C);
 /* depthwise Conv2d(C,C,3,pad 1,groups=C) (lunext.py:14-15,24), w9[t][c] fp32.  RAW_STATS: out = fp16(v) and
  * partial[blk][2][C] = (sum v, sum v^2); AFFINE_RELU: out = relu(v*scale + shift + x) (eval-mode block). */
 int uh_dwconv3x3_fwd(int B, int H, int W, int C, const void* x, int x_cstride, int x_coff,

@@ -485,3 +485,60 @@ def test_adam_step_matches_torch():
         torch.testing.assert_close(pd.cpu(), ref.detach(), rtol=1e-6, atol=1e-7)
     with pytest.raises(_lib.HipKernelError):
         call("uh_adam_step", n + 1, pd.data_ptr(), pd.data_ptr(), m.data_ptr(), v.data_ptr(), 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, S())
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 16, 16, 64), (1, 20, 12, 8), (3, 5, 7, 24), (2, 33, 31, 128), (1, 48, 48, 512)])
+def test_depthwise_conv_forward_backward(B, H, W, C):
+    """uh_dwconv3x3_fwd (both epilogues) / _dgrad / _wgrad against F.conv2d(groups=C) on the same bf16-rounded
+    operands; shapes whose rows do not fill the 16-row strips and whose width does not fill a workgroup."""
+    g = torch.Generator().manual_seed(B * 100 + H + C)
+    x = bf(torch.randn(B, C, H, W, generator=g))
+    w = torch.randn(C, 1, 3, 3, generator=g) / 3
+    bias = torch.randn(C, generator=g)
+    xa = act_from(x)
+    w9 = w.view(C, 9).t().contiguous().to(DEV)
+    mask = rowmask(B, H, W)
+    parts = lib.uh_dw_parts(B, H, W, C)
+    assert parts > 0 and lib.uh_dw_parts(B, H, W, C + 1) == 0
+    stat = torch.full((parts, 2, C), float("nan"), device=DEV)
+    y = new_act(B, H, W, C, DEV)
+    bd = bias.to(DEV)
+    call("uh_dwconv3x3_fwd", B, H, W, C, xa.ptr, xa.cstride, xa.coff, w9.data_ptr(), bd.data_ptr(), _lib.EPI_RAW_STATS,
+         None, None, mask.data_ptr(), y.ptr, y.cstride, y.coff, stat.data_ptr(), S())
+    torch.cuda.synchronize()
+    want = F.conv2d(x, w, bias, padding=1, groups=C)
+    close(y.to_nchw(half=True), want, 1e-3, "depthwise output (fp16 store)")
+    pads_are_zero(y)
+    s = stat.sum(0).cpu()
+    close(s[0], want.sum((0, 2, 3)), 1e-3, "sum v")
+    close(s[1], (want * want).sum((0, 2, 3)), 1e-3, "sum v^2")
+    # eval epilogue: relu(v*scale + shift + x)
+    sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    a = new_act(B, H, W, C, DEV)
+    scd, shd = sc.to(DEV), sh.to(DEV)       # named: a temporary's memory could be handed out again before the launch
+    call("uh_dwconv3x3_fwd", B, H, W, C, xa.ptr, xa.cstride, xa.coff, w9.data_ptr(), bd.data_ptr(), _lib.EPI_AFFINE_RELU,
+         scd.data_ptr(), shd.data_ptr(), mask.data_ptr(), a.ptr, a.cstride, a.coff, None, S())
+    torch.cuda.synchronize()
+    close(a.to_nchw(), torch.relu(want * sc.view(1, C, 1, 1) + sh.view(1, C, 1, 1) + x), 1e-2, "eval block output (bf16 store)")
+    pads_are_zero(a)
+    # input gradient with the residual branch added, and weight gradient
+    dy = bf(torch.randn(B, C, H, W, generator=g))
+    dr = bf(torch.randn(B, C, H, W, generator=g))
+    dya, dra = act_from(dy), act_from(dr)
+    dx = new_act(B, H, W, C, DEV)
+    call("uh_dwconv3x3_dgrad", B, H, W, C, dya.ptr, dya.cstride, dya.coff, w9.data_ptr(), dra.ptr, dra.cstride, dra.coff,
+         mask.data_ptr(), dx.ptr, dx.cstride, dx.coff, S())
+    wp = torch.full((parts, 9, C), float("nan"), device=DEV)
+    call("uh_dwconv3x3_wgrad", B, H, W, C, dya.ptr, dya.cstride, dya.coff, xa.ptr, xa.cstride, xa.coff, wp.data_ptr(), S())
+    torch.cuda.synchronize()
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    F.conv2d(xr, wr, None, padding=1, groups=C).backward(dy)
+    close(dx.to_nchw(), xr.grad + dr, 1e-2, "depthwise input gradient + residual (bf16 store)")
+    pads_are_zero(dx)
+    close(wp.sum(0).t().reshape(C, 1, 3, 3), wr.grad, 1e-3, "depthwise weight gradient")
+    # without a residual
+    call("uh_dwconv3x3_dgrad", B, H, W, C, dya.ptr, dya.cstride, dya.coff, w9.data_ptr(), None, 0, 0,
+         mask.data_ptr(), dx.ptr, dx.cstride, dx.coff, S())
+    torch.cuda.synchronize()
+    close(dx.to_nchw(), xr.grad, 1e-2, "depthwise input gradient")

@@ -40,9 +40,27 @@ __device__ __forceinline__ void block_combine_store(float (&acc)[NSTAT][8], int 
       for (int j = 0; j < 8; ++j) lds[(rr * NSTAT + s) * C + cc * 8 + j] = acc[s][j];
   }
   __syncthreads();
-  for (int i = tid; i < NSTAT * C; i += 256) {
+  const int ncol = NSTAT * C;
+  if (ncol <= 128 && rpi >= 16) {
+    // two levels: 256/ncol threads per column add a slice of the rows each, then one thread per column adds the
+    // slices (one level would be rpi additions one after the other by ncol threads: 256 deep when C = 8)
+    const int nseg = 256 / ncol, col = tid % ncol, seg = tid / ncol;
     float v = 0.f;
-    for (int r = 0; r < rpi; ++r) v += lds[r * NSTAT * C + i];
+    if (seg < nseg)
+      for (int r = seg; r < rpi; r += nseg) v += lds[r * ncol + col];
+    __syncthreads();
+    if (seg < nseg) lds[seg * ncol + col] = v;
+    __syncthreads();
+    if (tid < ncol) {
+      float t = 0.f;
+      for (int q = 0; q < nseg; ++q) t += lds[q * ncol + tid];
+      out_row[tid] = t;
+    }
+    return;
+  }
+  for (int i = tid; i < ncol; i += 256) {
+    float v = 0.f;
+    for (int r = 0; r < rpi; ++r) v += lds[r * ncol + i];
     out_row[i] = v;
   }
 }

@@ -82,7 +82,7 @@ class LUNeXtRun:
         rec = _DWRec()
         rec.name, rec.x, rec.a, rec.C, rec.Cp, rec.lvl, rec.w9 = name, x, a, C, Cp, lvl, w9
         rec.y = Ls.act(B, H, W, Cp)
-        parts = L.uh_dw_parts(x.Mp, Cp)
+        parts = L.uh_dw_parts(B, H, W, Cp)
         stat = Ls.f32(parts * 2 * Cp)
         call("uh_dwconv3x3_fwd", B, H, W, Cp, x.ptr, x.cstride, x.coff, w9.data_ptr(), bias.data_ptr(), EPI_RAW_STATS,
              None, None, mask.data_ptr(), rec.y.ptr, rec.y.cstride, rec.y.coff, stat.data_ptr(), s)
@@ -121,7 +121,7 @@ class LUNeXtRun:
         call("uh_bn_res_relu_bwd_apply", x.Mp, Cp, da.ptr, da.cstride, da.coff, y.ptr, y.cstride, y.coff, x.ptr,
              x.cstride, x.coff, *st, coef.data_ptr(), mask.data_ptr(), dy.ptr, dy.cstride, dy.coff, dr.ptr, dr.cstride,
              dr.coff, s)
-        wparts = L.uh_dw_parts(x.Mp, Cp)
+        wparts = L.uh_dw_parts(B, H, W, Cp)
         wp = Ls.f32(wparts * 9 * Cp)
         call("uh_dwconv3x3_wgrad", B, H, W, Cp, dy.ptr, dy.cstride, dy.coff, x.ptr, x.cstride, x.coff, wp.data_ptr(), s)
         w9g = Ls.f32(9 * Cp)
