@@ -180,10 +180,12 @@ int uh_head_bwd(int B, int H, int W, int C, int OC, const void* a, int a_cstride
  * The 3-channel full-resolution level is carried zero-padded to 8 channels. */
 /* workgroups (= rows of `partial`) of the depthwise forward and weight-gradient kernels */
 int uh_dw_parts(int B, int H, int W, int C);
-/* depthwise Conv2d(C,C,3,pad 1,groups=C) (lunext.py:14-15,24), w9[t][c] fp32.  RAW_STATS: out = fp16(v) and
- * partial[blk][2][C] = (sum v, sum v^2); AFFINE_RELU: out = relu(v*scale + shift + x) (eval-mode block). */
+/* depthwise Conv2d(C,C,3,pad 1,groups=C) (lunext.py:14-15,24).  w and bias are the module's own fp32 tensors
+ * ([c_real][1][3][3] and [c_real], 16-byte aligned); channels c_real..C-1 of the activations are zero padding.
+ * RAW_STATS: out = fp16(v) and partial[blk][2][C] = (sum v, sum v^2); AFFINE_RELU: out = relu(v*scale + shift + x)
+ * (eval-mode block; scale, shift of C floats). */
 int uh_dwconv3x3_fwd(int B, int H, int W, int C, const void* x, int x_cstride, int x_coff,
-                     const float* w9, const float* bias, int mode, const float* scale, const float* shift,
+                     const float* w, int c_real, const float* bias, int mode, const float* scale, const float* shift,
                      const uint8_t* rowmask, void* out, int o_cstride, int o_coff, float* partial, uh_stream s);
 /* a = relu(y*scale + shift + x)   (lunext.py:25-28) and its backward: d = da*(.. > 0);
  * reduce -> partial[P][2][C] (P = uh_bn_bwd_parts); apply -> dy = scale*(d - c0 - xhat*c1), dr = d */
@@ -199,9 +201,9 @@ int uh_bn_res_relu_bwd_apply(long long Mp, int C, const void* da, int da_cstride
                              const float* mean, const float* invstd, const float* scale, const float* shift,
                              const float* coef, const uint8_t* rowmask,
                              void* dy, int dy_cstride, int dy_coff, void* dr, int dr_cstride, int dr_coff, uh_stream s);
-/* dx = dwconv(dy, flipped w9) + dr;  partial[blk][9][C] = sum_m dy[m][c]*x[m+off(t)][c] (blk < uh_dw_parts) */
+/* dx = dwconv(dy, flipped w) + dr;  partial[blk][9][C] = sum_m dy[m][c]*x[m+off(t)][c] (blk < uh_dw_parts) */
 int uh_dwconv3x3_dgrad(int B, int H, int W, int C, const void* dy, int dy_cstride, int dy_coff,
-                       const float* w9, const void* dr, int dr_cstride, int dr_coff,
+                       const float* w, int c_real, const void* dr, int dr_cstride, int dr_coff,
                        const uint8_t* rowmask, void* dx, int dx_cstride, int dx_coff, uh_stream s);
 int uh_dwconv3x3_wgrad(int B, int H, int W, int C, const void* dy, int dy_cstride, int dy_coff,
                        const void* x, int x_cstride, int x_coff, float* partial, uh_stream s);

@@ -496,14 +496,14 @@ def test_depthwise_conv_forward_backward(B, H, W, C):
     w = torch.randn(C, 1, 3, 3, generator=g) / 3
     bias = torch.randn(C, generator=g)
     xa = act_from(x)
-    w9 = w.view(C, 9).t().contiguous().to(DEV)
+    wd = w.to(DEV)                       # the kernels read the module's own [C][1][3][3] layout
     mask = rowmask(B, H, W)
     parts = lib.uh_dw_parts(B, H, W, C)
     assert parts > 0 and lib.uh_dw_parts(B, H, W, C + 1) == 0
     stat = torch.full((parts, 2, C), float("nan"), device=DEV)
     y = new_act(B, H, W, C, DEV)
     bd = bias.to(DEV)
-    call("uh_dwconv3x3_fwd", B, H, W, C, xa.ptr, xa.cstride, xa.coff, w9.data_ptr(), bd.data_ptr(), _lib.EPI_RAW_STATS,
+    call("uh_dwconv3x3_fwd", B, H, W, C, xa.ptr, xa.cstride, xa.coff, wd.data_ptr(), C, bd.data_ptr(), _lib.EPI_RAW_STATS,
          None, None, mask.data_ptr(), y.ptr, y.cstride, y.coff, stat.data_ptr(), S())
     torch.cuda.synchronize()
     want = F.conv2d(x, w, bias, padding=1, groups=C)
@@ -516,7 +516,7 @@ def test_depthwise_conv_forward_backward(B, H, W, C):
     sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
     a = new_act(B, H, W, C, DEV)
     scd, shd = sc.to(DEV), sh.to(DEV)       # named: a temporary's memory could be handed out again before the launch
-    call("uh_dwconv3x3_fwd", B, H, W, C, xa.ptr, xa.cstride, xa.coff, w9.data_ptr(), bd.data_ptr(), _lib.EPI_AFFINE_RELU,
+    call("uh_dwconv3x3_fwd", B, H, W, C, xa.ptr, xa.cstride, xa.coff, wd.data_ptr(), C, bd.data_ptr(), _lib.EPI_AFFINE_RELU,
          scd.data_ptr(), shd.data_ptr(), mask.data_ptr(), a.ptr, a.cstride, a.coff, None, S())
     torch.cuda.synchronize()
     close(a.to_nchw(), torch.relu(want * sc.view(1, C, 1, 1) + sh.view(1, C, 1, 1) + x), 1e-2, "eval block output (bf16 store)")
@@ -526,7 +526,7 @@ def test_depthwise_conv_forward_backward(B, H, W, C):
     dr = bf(torch.randn(B, C, H, W, generator=g))
     dya, dra = act_from(dy), act_from(dr)
     dx = new_act(B, H, W, C, DEV)
-    call("uh_dwconv3x3_dgrad", B, H, W, C, dya.ptr, dya.cstride, dya.coff, w9.data_ptr(), dra.ptr, dra.cstride, dra.coff,
+    call("uh_dwconv3x3_dgrad", B, H, W, C, dya.ptr, dya.cstride, dya.coff, wd.data_ptr(), C, dra.ptr, dra.cstride, dra.coff,
          mask.data_ptr(), dx.ptr, dx.cstride, dx.coff, S())
     wp = torch.full((parts, 9, C), float("nan"), device=DEV)
     call("uh_dwconv3x3_wgrad", B, H, W, C, dya.ptr, dya.cstride, dya.coff, xa.ptr, xa.cstride, xa.coff, wp.data_ptr(), S())
@@ -538,7 +538,44 @@ def test_depthwise_conv_forward_backward(B, H, W, C):
     pads_are_zero(dx)
     close(wp.sum(0).t().reshape(C, 1, 3, 3), wr.grad, 1e-3, "depthwise weight gradient")
     # without a residual
-    call("uh_dwconv3x3_dgrad", B, H, W, C, dya.ptr, dya.cstride, dya.coff, w9.data_ptr(), None, 0, 0,
+    call("uh_dwconv3x3_dgrad", B, H, W, C, dya.ptr, dya.cstride, dya.coff, wd.data_ptr(), C, None, 0, 0,
          mask.data_ptr(), dx.ptr, dx.cstride, dx.coff, S())
     torch.cuda.synchronize()
     close(dx.to_nchw(), xr.grad, 1e-2, "depthwise input gradient")
+
+
+def test_depthwise_conv_padded_channels():
+    """The 3-channel level: activations carry 8 channels (5 of them zero), weight and bias have 3."""
+    B, H, W, C, Cp = 2, 20, 28, 3, 8
+    g = torch.Generator().manual_seed(5)
+    x = bf(torch.randn(B, C, H, W, generator=g))
+    w = torch.randn(C, 1, 3, 3, generator=g) / 3
+    bias = torch.randn(C, generator=g)
+    xp = torch.zeros(B, Cp, H, W)
+    xp[:, :C] = x
+    xa = act_from(xp)
+    wd, bd = w.to(DEV), bias.to(DEV)
+    mask = rowmask(B, H, W)
+    parts = lib.uh_dw_parts(B, H, W, Cp)
+    stat = torch.zeros(parts, 2, Cp, device=DEV)
+    y = new_act(B, H, W, Cp, DEV)
+    call("uh_dwconv3x3_fwd", B, H, W, Cp, xa.ptr, xa.cstride, xa.coff, wd.data_ptr(), C, bd.data_ptr(), _lib.EPI_RAW_STATS,
+         None, None, mask.data_ptr(), y.ptr, y.cstride, y.coff, stat.data_ptr(), S())
+    dy = bf(torch.randn(B, Cp, H, W, generator=g))
+    dya = act_from(dy)
+    dx = new_act(B, H, W, Cp, DEV)
+    call("uh_dwconv3x3_dgrad", B, H, W, Cp, dya.ptr, dya.cstride, dya.coff, wd.data_ptr(), C, None, 0, 0,
+         mask.data_ptr(), dx.ptr, dx.cstride, dx.coff, S())
+    torch.cuda.synchronize()
+    want = F.conv2d(x, w, bias, padding=1, groups=C)
+    got = y.to_nchw(half=True)
+    close(got[:, :C], want, 1e-3, "real channels")
+    assert got[:, C:].abs().max().item() == 0, "padding channels stay zero"
+    xr = x.clone().requires_grad_(True)
+    F.conv2d(xr, w, None, padding=1, groups=C).backward(dy[:, :C])
+    gx = dx.to_nchw()
+    close(gx[:, :C], xr.grad, 1e-2, "input gradient, real channels")
+    assert gx[:, C:].abs().max().item() == 0
+    with pytest.raises(_lib.HipKernelError):
+        call("uh_dwconv3x3_fwd", B, H, W, Cp, xa.ptr, xa.cstride, xa.coff, wd.data_ptr(), Cp + 1, bd.data_ptr(),
+             _lib.EPI_RAW_STATS, None, None, mask.data_ptr(), y.ptr, y.cstride, y.coff, stat.data_ptr(), S())

@@ -54,11 +54,11 @@ SIGNATURES = {
     "uh_head_bwd_parts": (I, [I, I, I, I]),
     "uh_head_bwd": (I, [I, I, I, I, I, P, I, I, P, P, P, I, I, P, P]),
     "uh_dw_parts": (I, [I, I, I, I]),
-    "uh_dwconv3x3_fwd": (I, [I, I, I, I, P, I, I, P, P, I, P, P, P, P, I, I, P, P]),
+    "uh_dwconv3x3_fwd": (I, [I, I, I, I, P, I, I, P, I, P, I, P, P, P, P, I, I, P, P]),
     "uh_bn_res_relu_apply": (I, [L, I, P, I, I, P, I, I, P, P, P, P, I, I, P]),
     "uh_bn_res_relu_bwd_reduce": (I, [L, I, P, I, I, P, I, I, P, I, I, P, P, P, P, P, P]),
     "uh_bn_res_relu_bwd_apply": (I, [L, I, P, I, I, P, I, I, P, I, I, P, P, P, P, P, P, P, I, I, P, I, I, P]),
-    "uh_dwconv3x3_dgrad": (I, [I, I, I, I, P, I, I, P, P, I, I, P, P, I, I, P]),
+    "uh_dwconv3x3_dgrad": (I, [I, I, I, I, P, I, I, P, I, P, I, I, P, P, I, I, P]),
     "uh_dwconv3x3_wgrad": (I, [I, I, I, I, P, I, I, P, I, I, P, P]),
     "uh_gate_fwd": (I, [L, I, P, I, I, P, I, I, P, I, I, P]),
     "uh_gate_bwd": (I, [L, I, P, I, I, P, I, I, P, I, I, P, P, I, I, P, I, I, P]),

@@ -243,11 +243,13 @@ struct BwdArgs {
 
 __global__ __launch_bounds__(256) void skel_bwd_level_kernel(BwdArgs a) {
   constexpr int N3 = BT + 6, N2 = BT + 4, N1 = BT + 2;
-  __shared__ float sE1[N3 * N3];    // E_{k+1}, halo 3
-  __shared__ float sE[N2 * N2];     // E_k, halo 2
+  __shared__ float sE1[N3 * N3];    // E_{k+1}, halo 3; -inf outside the image (never a maximum)
+  __shared__ float sE[N2 * N2];     // E_k, halo 2; +inf outside the image (never a minimum)
   __shared__ float sGD[N2 * N2];    // dL/dD_k, halo 2
   __shared__ signed char sAM[N2 * N2];  // arg-max slot (0..8) of the 3x3 window of E_{k+1} at each position, halo 2
-  __shared__ float sG1[N1 * N1];    // complete dL/dE_{k+1}, halo 1
+  __shared__ float sGV[N1 * N1];    // halo 1: dL/dE_{k+1}(q) times the share of the vertical minimum of window q
+  __shared__ float sGH[N1 * N1];    //         ... of the horizontal minimum
+  __shared__ signed char sRT[N1 * N1];  // where those minima sit: (varg + 1) | (harg + 1) << 2; 15 outside the image
   __shared__ float sDir[BT * BT];   // direct term dL/ddelta_k * mask at the core
   const Img g{a.H, a.W};
   const int tid = threadIdx.x;
@@ -259,11 +261,11 @@ __global__ __launch_bounds__(256) void skel_bwd_level_kernel(BwdArgs a) {
 
   for (int i = tid; i < N3 * N3; i += 256) {
     const int y = y0 - 3 + i / N3, x = x0 - 3 + i % N3;
-    sE1[i] = g.in(y, x) ? ek1[y * a.W + x] : 0.f;
+    sE1[i] = g.in(y, x) ? ek1[y * a.W + x] : -INFINITY;
   }
   for (int i = tid; i < N2 * N2; i += 256) {
     const int y = y0 - 2 + i / N2, x = x0 - 2 + i % N2;
-    float v = 0.f;
+    float v = INFINITY;
     if (g.in(y, x)) {
       v = ek[y * a.W + x];
       if (a.level0) v = clamp01(v);
@@ -282,16 +284,13 @@ __global__ __launch_bounds__(256) void skel_bwd_level_kernel(BwdArgs a) {
       // 3x3 window of E_{k+1} in row-major order, first maximum wins
       float best = -INFINITY;
 #pragma unroll
-      for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-        for (int dx = -1; dx <= 1; ++dx) {
-          if (!g.in(y + dy, x + dx)) continue;
-          const float v = sE1[(ly + 1 + dy) * N3 + lx + 1 + dx];
-          if (v > best) {
-            best = v;
-            am = (dy + 1) * 3 + dx + 1;
-          }
+      for (int t = 0; t < 9; ++t) {
+        const float v = sE1[(ly + t / 3) * N3 + lx + t % 3];
+        if (v > best) {
+          best = v;
+          am = t;
         }
+      }
       const float e = sE[i];
       const float diff = e - best;
       const float delta = fmaxf(diff, 0.f);
@@ -303,76 +302,81 @@ __global__ __launch_bounds__(256) void skel_bwd_level_kernel(BwdArgs a) {
         gs = a.gs_in[gi];
       }
       float gdelta = gs;
+      const bool core = (ly >= 2 && ly < 2 + BT && lx >= 2 && lx < 2 + BT);
       if (a.skel_prev) {
         const float sp = a.skel_prev[gi];
         const float prod = sp * delta;
         const bool on = (delta - prod) > 0.f;
         gdelta = on ? gs * (1.f - sp) : 0.f;
-        const bool core = (ly >= 2 && ly < 2 + BT && lx >= 2 && lx < 2 + BT);
         if (core) a.gs_out[gi] = on ? gs * (1.f - delta) : gs;
       }
       const float dmask = diff > 0.f ? gdelta : 0.f;
       gd = -dmask;
-      if (ly >= 2 && ly < 2 + BT && lx >= 2 && lx < 2 + BT) sDir[(ly - 2) * BT + lx - 2] = dmask;
+      if (core) sDir[(ly - 2) * BT + lx - 2] = dmask;
     }
     sGD[i] = gd;
     sAM[i] = (signed char)am;
   }
   __syncthreads();
 
-  // stage B: complete dL/dE_{k+1} on core+1 = incoming part + dilation windows whose arg-max is this position
+  // stage B on core+1: complete dL/dE_{k+1}(q) = incoming part + the dilation windows whose arg-max is q, and how
+  // window q of the erosion E_{k+1} = erode(E_k) routes it: min(vertical min, horizontal min), torch.min splits a tie
+  // 1/2 : 1/2, inside each 3-window the FIRST minimum (top/left, centre, bottom/right) takes the gradient
   for (int i = tid; i < N1 * N1; i += 256) {
     const int ly = i / N1, lx = i % N1;
     const int y = y0 - 1 + ly, x = x0 - 1 + lx;
-    float v = 0.f;
+    float gv = 0.f, gh = 0.f;
+    int code = 15;
     if (g.in(y, x)) {
-      if (a.ge1_in) v = a.ge1_in[plane + (long long)y * a.W + x];
+      float v = a.ge1_in ? a.ge1_in[plane + (long long)y * a.W + x] : 0.f;
 #pragma unroll
       for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
         for (int dx = -1; dx <= 1; ++dx) {
-          // window centred at q = p + (dy,dx); p sits at slot (-dy+1)*3 + (-dx+1) of that window
+          // window centred at q + (dy,dx); q sits at slot (-dy+1)*3 + (-dx+1) of that window
           const int qi = (ly + 1 + dy) * N2 + lx + 1 + dx;
           if (sAM[qi] == (1 - dy) * 3 + (1 - dx)) v += sGD[qi];
         }
+      const int ci = (ly + 1) * N2 + lx + 1;               // q in sE coordinates
+      const float c = sE[ci];
+      float vmin = sE[ci - N2];
+      int varg = -1;
+      if (c < vmin) { vmin = c; varg = 0; }
+      { const float b = sE[ci + N2]; if (b < vmin) { vmin = b; varg = 1; } }
+      float hmin = sE[ci - 1];
+      int harg = -1;
+      if (c < hmin) { hmin = c; harg = 0; }
+      { const float b = sE[ci + 1]; if (b < hmin) { hmin = b; harg = 1; } }
+      const float wv = vmin < hmin ? 1.f : (vmin == hmin ? 0.5f : 0.f);
+      gv = v * wv;
+      gh = v * (1.f - wv);
+      code = (varg + 1) | ((harg + 1) << 2);
     }
-    sG1[i] = v;
+    sGV[i] = gv;
+    sGH[i] = gh;
+    sRT[i] = (signed char)code;
   }
   __syncthreads();
 
-  // stage C: route dL/dE_{k+1} through E_{k+1} = erode(E_k) back to E_k at the core
+  // stage C at the core: p collects from the five erosion windows that contain it (centred at p, above, below, left,
+  // right of p, in that order) the shares whose minimum sits on p
   for (int i = tid; i < BT * BT; i += 256) {
     const int cy = i / BT, cx = i % BT;
     const int y = y0 + cy, x = x0 + cx;
     if (!g.in(y, x)) continue;
     float acc = sDir[i];
-    // the five erosion windows that contain p: centred at p, p+-row, p+-col
-    const int qdy[5] = {0, -1, 1, 0, 0}, qdx[5] = {0, 0, 0, -1, 1};
-#pragma unroll
-    for (int w = 0; w < 5; ++w) {
-      const int qy = y + qdy[w], qx = x + qdx[w];
-      if (!g.in(qy, qx)) continue;
-      const int ly = cy + 2 + qdy[w], lx = cx + 2 + qdx[w];      // q in sE coordinates
-      const float gq = sG1[(cy + 1 + qdy[w]) * N1 + cx + 1 + qdx[w]];
-      const float c = sE[ly * N2 + lx];
-      // vertical minimum: order top, centre, bottom; first minimum wins
-      float vmin = INFINITY;
-      int varg = 0;
-      if (qy > 0) { vmin = sE[(ly - 1) * N2 + lx]; varg = -1; }
-      if (c < vmin) { vmin = c; varg = 0; }
-      if (qy + 1 < a.H) { const float b = sE[(ly + 1) * N2 + lx]; if (b < vmin) { vmin = b; varg = 1; } }
-      // horizontal minimum: order left, centre, right
-      float hmin = INFINITY;
-      int harg = 0;
-      if (qx > 0) { hmin = sE[ly * N2 + lx - 1]; harg = -1; }
-      if (c < hmin) { hmin = c; harg = 0; }
-      if (qx + 1 < a.W) { const float b = sE[ly * N2 + lx + 1]; if (b < hmin) { hmin = b; harg = 1; } }
-      const float wv = vmin < hmin ? 1.f : (vmin == hmin ? 0.5f : 0.f);
-      const float wh = 1.f - wv;
-      // does the vertical / horizontal arg-min of window q land on p?   p = q - (qdy,qdx)
-      if (qdx[w] == 0 && varg == -qdy[w]) acc += gq * wv;
-      if (qdy[w] == 0 && harg == -qdx[w]) acc += gq * wh;
-    }
+    const int q = (cy + 1) * N1 + cx + 1;
+    int c = sRT[q];
+    if ((c & 3) == 1) acc += sGV[q];
+    if ((c >> 2) == 1) acc += sGH[q];
+    c = sRT[q - N1];                                        // window above: p is its bottom row
+    if (c != 15 && (c & 3) == 2) acc += sGV[q - N1];
+    c = sRT[q + N1];                                        // window below: p is its top row
+    if (c != 15 && (c & 3) == 0) acc += sGV[q + N1];
+    c = sRT[q - 1];                                         // window to the left: p is its right column
+    if (c != 15 && (c >> 2) == 2) acc += sGH[q - 1];
+    c = sRT[q + 1];                                         // window to the right: p is its left column
+    if (c != 15 && (c >> 2) == 0) acc += sGH[q + 1];
     const long long gi = plane + (long long)y * a.W + x;
     if (a.level0) {
       const float raw = ek[y * a.W + x];

@@ -51,6 +51,36 @@ __device__ __forceinline__ void dw_load8f(const float* __restrict__ p, float (&f
 #pragma unroll
   for (int j = 0; j < 4; ++j) { f[j] = a[j]; f[4 + j] = b[j]; }
 }
+// the 3x3 filters of channels c0 .. c0+7 from the module's own [C_real][1][3][3] fp32 weight (channel c at w + 9 c);
+// channels >= c_real (zero padding of the 3-channel level) get zero filters
+__device__ __forceinline__ void dw_load_filters(const float* __restrict__ wt, int c0, int c_real, float (&w)[9][8]) {
+  if (c0 + 8 <= c_real) {
+    float flat[72];
+#pragma unroll
+    for (int q = 0; q < 18; ++q) {
+      const f32x4 v = *(const f32x4*)(wt + c0 * 9 + 4 * q);     // 288 bytes per thread: 16-byte aligned
+#pragma unroll
+      for (int e = 0; e < 4; ++e) flat[4 * q + e] = v[e];
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w[t][j] = flat[j * 9 + t];
+  } else {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w[t][j] = (c0 + j < c_real) ? wt[(c0 + j) * 9 + t] : 0.f;
+  }
+}
+__device__ __forceinline__ void dw_load8f_guarded(const float* __restrict__ p, int c0, int c_real, float (&f)[8]) {
+  if (c0 + 8 <= c_real) {
+    dw_load8f(p + c0, f);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (c0 + j < c_real) ? p[c0 + j] : 0.f;
+  }
+}
 // positions m-1, m, m+1 of one row (p points at position m), 8 channels each, as floats
 __device__ __forceinline__ void dw_load3(const char* __restrict__ p, long long cs2, float (&f)[3][8]) {
   unpack8(*(const U4*)(p - cs2), f[0]);
@@ -58,11 +88,11 @@ __device__ __forceinline__ void dw_load3(const char* __restrict__ p, long long c
   unpack8(*(const U4*)(p + cs2), f[2]);
 }
 
-// v = sum_t x[m+off(t)][c]*w9[t][c] + bias[c];  train (RAW_STATS): out = fp16(v) + per-workgroup (sum v, sum v^2);
+// v = sum_t x[m+off(t)][c]*w[c][t] + bias[c];  train (RAW_STATS): out = fp16(v) + per-workgroup (sum v, sum v^2);
 // eval (AFFINE_RELU): out = bf16(relu(v*scale + shift + x[m][c])).
 template <int MODE>
 __global__ __launch_bounds__(256) void dwconv_fwd_kernel(long long Mp, int C, int Wp, const char* __restrict__ x,
-                                                         int x_cs, int x_co, const float* __restrict__ w9,
+                                                         int x_cs, int x_co, const float* __restrict__ wt, int c_real,
                                                          const float* __restrict__ bias,
                                                          const float* __restrict__ scale,
                                                          const float* __restrict__ shift,
@@ -77,13 +107,12 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(long long Mp, int C, in
     float w[9][8], b[8], sc[8], sh[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) b[j] = sc[j] = sh[j] = 0.f;
-    if (bias) dw_load8f(bias + g.cc * 8, b);
+    if (bias) dw_load8f_guarded(bias, g.cc * 8, c_real, b);
     if (MODE == UH_EPI_AFFINE_RELU) {
       dw_load8f(scale + g.cc * 8, sc);
       dw_load8f(shift + g.cc * 8, sh);
     }
-#pragma unroll
-    for (int t = 0; t < 9; ++t) dw_load8f(w9 + t * C + g.cc * 8, w[t]);
+    dw_load_filters(wt, g.cc * 8, c_real, w);
     const long long xs2 = (long long)x_cs * 2, os2 = (long long)o_cs * 2;
     const long long xrow = xs2 * Wp, orow = os2 * Wp;
     const char* xp = x + (g.m * x_cs + x_co + g.cc * 8) * 2;
@@ -142,11 +171,12 @@ extern "C" int uh_dw_parts(int B, int H, int W, int C) {
 }
 
 extern "C" int uh_dwconv3x3_fwd(int B, int H, int W, int C, const void* x, int x_cstride, int x_coff,
-                                const float* w9, const float* bias, int mode, const float* scale, const float* shift,
+                                const float* w, int c_real, const float* bias, int mode, const float* scale, const float* shift,
                                 const uint8_t* rowmask, void* out, int o_cstride, int o_coff, float* partial,
                                 uh_stream s) {
   EW_CHECK("dwconv3x3_fwd", C);
-  UH_REQUIRE(B > 0 && H > 0 && W > 0 && x && w9 && rowmask && out, "dwconv3x3_fwd: bad arguments");
+  UH_REQUIRE(B > 0 && H > 0 && W > 0 && x && w && rowmask && out, "dwconv3x3_fwd: bad arguments");
+  UH_REQUIRE(c_real > 0 && c_real <= C && ((uintptr_t)w & 15) == 0, "dwconv3x3_fwd: c_real=%d of C=%d, w 16-byte aligned", c_real, C);
   UH_REQUIRE(mode == UH_EPI_RAW_STATS || mode == UH_EPI_AFFINE_RELU, "dwconv3x3_fwd: bad mode %d", mode);
   UH_REQUIRE(mode != UH_EPI_RAW_STATS || partial, "dwconv3x3_fwd: RAW_STATS needs partial");
   UH_REQUIRE(mode != UH_EPI_AFFINE_RELU || (scale && shift), "dwconv3x3_fwd: AFFINE_RELU needs scale/shift");
@@ -154,12 +184,12 @@ extern "C" int uh_dwconv3x3_fwd(int B, int H, int W, int C, const void* x, int x
   const int rpi = ew_rows_per_iter(C);
   if (mode == UH_EPI_RAW_STATS)
     hipLaunchKernelGGL(dwconv_fwd_kernel<UH_EPI_RAW_STATS>, dw_grid(B, H, W, C), dim3(256), (size_t)rpi * 2 * C * 4,
-                       (hipStream_t)s, Mp, C, W + 1, (const char*)x, x_cstride, x_coff, w9, bias, scale, shift, rowmask,
-                       (char*)out, o_cstride, o_coff, partial);
+                       (hipStream_t)s, Mp, C, W + 1, (const char*)x, x_cstride, x_coff, w, c_real, bias, scale, shift,
+                       rowmask, (char*)out, o_cstride, o_coff, partial);
   else
     hipLaunchKernelGGL(dwconv_fwd_kernel<UH_EPI_AFFINE_RELU>, dw_grid(B, H, W, C), dim3(256), 0, (hipStream_t)s, Mp, C,
-                       W + 1, (const char*)x, x_cstride, x_coff, w9, bias, scale, shift, rowmask, (char*)out, o_cstride,
-                       o_coff, partial);
+                       W + 1, (const char*)x, x_cstride, x_coff, w, c_real, bias, scale, shift, rowmask, (char*)out,
+                       o_cstride, o_coff, partial);
   return uh_check_launch("dwconv3x3_fwd");
 }
 
@@ -313,17 +343,16 @@ extern "C" int uh_bn_res_relu_bwd_apply(long long Mp, int C, const void* da, int
   return uh_check_launch("bn_res_relu_bwd_apply");
 }
 
-// dx[m][c] = sum_t dy[m - off(t)][c]*w9[t][c] + dr[m][c]   (same strip walk as the forward kernel)
+// dx[m][c] = sum_t dy[m - off(t)][c]*w[c][t] + dr[m][c]   (same strip walk as the forward kernel)
 __global__ __launch_bounds__(256) void dwconv_dgrad_kernel(long long Mp, int C, int Wp, const char* __restrict__ dy,
-                                                           int dy_cs, int dy_co, const float* __restrict__ w9,
+                                                           int dy_cs, int dy_co, const float* __restrict__ wt, int c_real,
                                                            const char* __restrict__ dr, int dr_cs, int dr_co,
                                                            const uint8_t* __restrict__ rowmask,
                                                            char* __restrict__ dx, int dx_cs, int dx_co) {
   const DwGeo g = dw_geo(Mp, C, Wp);
   if (g.nr <= 0) return;
   float w[9][8];
-#pragma unroll
-  for (int t = 0; t < 9; ++t) dw_load8f(w9 + t * C + g.cc * 8, w[t]);
+  dw_load_filters(wt, g.cc * 8, c_real, w);
   const long long gs2 = (long long)dy_cs * 2, grow = gs2 * Wp;
   const long long rrow = (long long)dr_cs * 2 * Wp, orow = (long long)dx_cs * 2 * Wp;
   const char* gp = dy + (g.m * dy_cs + dy_co + g.cc * 8) * 2;
@@ -370,13 +399,14 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_kernel(long long Mp, int C, 
 }
 
 extern "C" int uh_dwconv3x3_dgrad(int B, int H, int W, int C, const void* dy, int dy_cstride, int dy_coff,
-                                  const float* w9, const void* dr, int dr_cstride, int dr_coff,
+                                  const float* w, int c_real, const void* dr, int dr_cstride, int dr_coff,
                                   const uint8_t* rowmask, void* dx, int dx_cstride, int dx_coff, uh_stream s) {
   EW_CHECK("dwconv3x3_dgrad", C);
-  UH_REQUIRE(B > 0 && H > 0 && W > 0 && dy && w9 && rowmask && dx, "dwconv3x3_dgrad: bad arguments");
+  UH_REQUIRE(B > 0 && H > 0 && W > 0 && dy && w && rowmask && dx, "dwconv3x3_dgrad: bad arguments");
+  UH_REQUIRE(c_real > 0 && c_real <= C && ((uintptr_t)w & 15) == 0, "dwconv3x3_dgrad: c_real=%d of C=%d, w 16-byte aligned", c_real, C);
   const long long Mp = uh_mp(B, H, W);
   hipLaunchKernelGGL(dwconv_dgrad_kernel, dw_grid(B, H, W, C), dim3(256), 0, (hipStream_t)s, Mp, C, W + 1,
-                     (const char*)dy, dy_cstride, dy_coff, w9, (const char*)dr, dr_cstride, dr_coff, rowmask,
+                     (const char*)dy, dy_cstride, dy_coff, w, c_real, (const char*)dr, dr_cstride, dr_coff, rowmask,
                      (char*)dx, dx_cstride, dx_coff);
   return uh_check_launch("dwconv3x3_dgrad");
 }

@@ -34,7 +34,7 @@ def _padv(t, n, fill=0.0):
 
 
 class _DWRec:
-    __slots__ = ("name", "x", "y", "a", "C", "Cp", "lvl", "w9", "mean", "invstd", "scale", "shift")
+    __slots__ = ("name", "x", "y", "a", "C", "Cp", "lvl", "wt", "mean", "invstd", "scale", "shift")
 
 
 class LUNeXtRun:
@@ -63,10 +63,9 @@ class LUNeXtRun:
         B, H, W = self.geo[lvl]
         C, Cp = blk.depthwise.out_channels, x.C
         s, Ls = _stream(), self.lease
-        w9 = Ls.f32(9 * Cp).view(9, Cp)
-        w9.zero_()
-        w9[:, :C] = blk.depthwise.weight.detach().view(C, 9).t()
-        bias = _padv(blk.depthwise.bias, Cp)
+        wt, bias = blk.depthwise.weight.detach(), blk.depthwise.bias.detach()      # read in place by the kernels
+        if wt.data_ptr() % 16 or not wt.is_contiguous():
+            wt = wt.clone(memory_format=torch.contiguous_format)
         gamma, beta = _padv(blk.bn.weight, Cp), _padv(blk.bn.bias, Cp)
         mask = self.masks[lvl]
         a = Ls.act(B, H, W, Cp)
@@ -75,16 +74,16 @@ class LUNeXtRun:
             f = Ls.f32(2 * Cp)
             call("uh_bn_fold_eval", Cp, gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(), None, BN_EPS,
                  f[:Cp].data_ptr(), f[Cp:].data_ptr(), s)
-            call("uh_dwconv3x3_fwd", B, H, W, Cp, x.ptr, x.cstride, x.coff, w9.data_ptr(), bias.data_ptr(),
+            call("uh_dwconv3x3_fwd", B, H, W, Cp, x.ptr, x.cstride, x.coff, wt.data_ptr(), C, bias.data_ptr(),
                  EPI_AFFINE_RELU, f[:Cp].data_ptr(), f[Cp:].data_ptr(), mask.data_ptr(), a.ptr, a.cstride, a.coff,
                  None, s)
             return a
         rec = _DWRec()
-        rec.name, rec.x, rec.a, rec.C, rec.Cp, rec.lvl, rec.w9 = name, x, a, C, Cp, lvl, w9
+        rec.name, rec.x, rec.a, rec.C, rec.Cp, rec.lvl, rec.wt = name, x, a, C, Cp, lvl, wt
         rec.y = Ls.act(B, H, W, Cp)
         parts = L.uh_dw_parts(B, H, W, Cp)
         stat = Ls.f32(parts * 2 * Cp)
-        call("uh_dwconv3x3_fwd", B, H, W, Cp, x.ptr, x.cstride, x.coff, w9.data_ptr(), bias.data_ptr(), EPI_RAW_STATS,
+        call("uh_dwconv3x3_fwd", B, H, W, Cp, x.ptr, x.cstride, x.coff, wt.data_ptr(), C, bias.data_ptr(), EPI_RAW_STATS,
              None, None, mask.data_ptr(), rec.y.ptr, rec.y.cstride, rec.y.coff, stat.data_ptr(), s)
         f = Ls.f32(4 * Cp)
         rec.mean, rec.invstd, rec.scale, rec.shift = f[:Cp], f[Cp:2 * Cp], f[2 * Cp:3 * Cp], f[3 * Cp:]
@@ -113,10 +112,18 @@ class LUNeXtRun:
         st = (rec.mean.data_ptr(), rec.invstd.data_ptr(), rec.scale.data_ptr(), rec.shift.data_ptr())
         call("uh_bn_res_relu_bwd_reduce", x.Mp, Cp, da.ptr, da.cstride, da.coff, y.ptr, y.cstride, y.coff, x.ptr,
              x.cstride, x.coff, *st, partial.data_ptr(), s)
-        dg, db, coef = Ls.f32(Cp), Ls.f32(Cp), Ls.f32(2 * Cp)
+        coef = Ls.f32(2 * Cp)
+        if Cp == C:                                  # no channel padding: the kernel writes the gradient tensors themselves
+            dg = torch.empty(C, dtype=torch.float32, device=self.device)
+            db = torch.empty(C, dtype=torch.float32, device=self.device)
+        else:
+            dg, db = Ls.f32(Cp), Ls.f32(Cp)
         call("uh_bn_bwd_finalize", partial.data_ptr(), parts, Cp, B * H * W, dg.data_ptr(), db.data_ptr(),
              coef.data_ptr(), 0, s)
-        grads[name + ".bn.weight"], grads[name + ".bn.bias"] = dg[:C].clone(), db[:C].clone()
+        if Cp == C:
+            grads[name + ".bn.weight"], grads[name + ".bn.bias"] = dg, db
+        else:
+            grads[name + ".bn.weight"], grads[name + ".bn.bias"] = dg[:C].clone(), db[:C].clone()
         dy, dr = Ls.act(B, H, W, Cp), Ls.act(B, H, W, Cp)
         call("uh_bn_res_relu_bwd_apply", x.Mp, Cp, da.ptr, da.cstride, da.coff, y.ptr, y.cstride, y.coff, x.ptr,
              x.cstride, x.coff, *st, coef.data_ptr(), mask.data_ptr(), dy.ptr, dy.cstride, dy.coff, dr.ptr, dr.cstride,
@@ -128,9 +135,9 @@ class LUNeXtRun:
         call("uh_colsum_finalize", wp.data_ptr(), wparts, 9 * Cp, 1, w9g.data_ptr(), 0, s)
         grads[name + ".depthwise.weight"] = w9g.view(9, Cp)[:, :C].t().reshape(C, 1, 3, 3).contiguous()
         # conv bias in front of train-mode BatchNorm: exactly zero gradient
-        grads[name + ".depthwise.bias"] = torch.zeros(C, dtype=torch.float32, device=self.device)
+        grads[name + ".depthwise.bias"] = self._zeros(C)
         dx = Ls.act(B, H, W, Cp)
-        call("uh_dwconv3x3_dgrad", B, H, W, Cp, dy.ptr, dy.cstride, dy.coff, rec.w9.data_ptr(), dr.ptr, dr.cstride,
+        call("uh_dwconv3x3_dgrad", B, H, W, Cp, dy.ptr, dy.cstride, dy.coff, rec.wt.data_ptr(), C, dr.ptr, dr.cstride,
              dr.coff, mask.data_ptr(), dx.ptr, dx.cstride, dx.coff, s)
         return dx
 
@@ -219,6 +226,15 @@ class LUNeXtRun:
         call("uh_conv_gemm", Bs, Hs, Ws, d4.ptr, d4.cstride, 0, N, wd.data_ptr(), cin, 1, EPI_MASKED, dx.ptr,
              dx.cstride, dx.coff, None, None, None, None, self.masks[l + 1].data_ptr(), s)
         return dx
+
+    def _zeros(self, n):
+        """n zeros out of one per-run buffer (gradients that are identically zero; nothing writes to them)."""
+        if getattr(self, "_zero_pool", None) is None or self._zero_used + n > self._zero_pool.numel():
+            self._zero_pool = torch.zeros(max(4096, n), dtype=torch.float32, device=self.device)
+            self._zero_used = 0
+        out = self._zero_pool[self._zero_used:self._zero_used + n]
+        self._zero_used += n
+        return out
 
     def _colsum(self, a, C):
         s, Ls = _stream(), self.lease
