@@ -6,6 +6,11 @@ library has not been built (``make -C unet_amd/csrc``); there is no CPU or eager
 import ctypes
 import os
 
+# torch first: its wheel ships its own HIP runtime (libamdhip64), and the kernels must register with the runtime
+# that owns torch's streams and allocations.  Loaded the other way round, libunet_hip.so pulls in the system runtime,
+# the process ends up with two, and every launch on a torch stream fails with "no ROCm-capable device is detected".
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UNET_HIP_LIB") or os.path.join(_HERE, "libunet_hip.so")   # override: kernel experiments
 
