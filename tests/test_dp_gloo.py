@@ -94,3 +94,55 @@ def test_bucket_layout():
     for x in b.buckets:
         assert x["tensor"].data_ptr() == b.flat.data_ptr() + off * 4
         off += x["tensor"].numel()
+
+
+class _Toy(nn.Module):
+    """three used layers and one that never takes part in forward (like LUNeXt's att*.output_conv)"""
+
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Linear(6, 5)
+        self.unused = nn.Linear(5, 5)
+        self.b = nn.Linear(5, 3)
+        self.c = nn.Linear(3, 1)
+
+    def forward(self, x):
+        return self.c(torch.tanh(self.b(torch.tanh(self.a(x)))))
+
+
+def _avg_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from unet_amd.dp import GradAverager
+    torch.manual_seed(7 + rank)                   # different weights per rank until the broadcast
+    model = _Toy()
+    avg = GradAverager(model.parameters(), bucket_bytes=64)      # tiny buckets: several of them, one holding `unused`
+    assert len(avg.buckets) >= 3
+    avg.broadcast_from_rank0(model)
+    g = torch.Generator().manual_seed(100 + rank)
+    x, y = torch.randn(4, 6, generator=g), torch.randn(4, 1, generator=g)
+    for step in range(2):                          # twice: stale bucket contents must not leak into the second mean
+        model.zero_grad(set_to_none=True)
+        nn.functional.mse_loss(model(x * (step + 1)), y).backward()
+        local = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        avg.average()
+        torch.save({"local": local, "mean": {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None},
+                    "w": model.a.weight.detach().clone(), "none": [n for n, p in model.named_parameters() if p.grad is None]},
+                   os.path.join(out_dir, f"avg{rank}_{step}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_grad_averager_world2_with_unused_parameters(tmp_path):
+    world = 2
+    mp.spawn(_avg_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for step in range(2):
+        r = [torch.load(os.path.join(str(tmp_path), f"avg{k}_{step}.pt")) for k in range(world)]
+        assert torch.equal(r[0]["w"], r[1]["w"])                       # same weights after the broadcast
+        assert r[0]["none"] == r[1]["none"] == ["unused.weight", "unused.bias"]
+        for n in r[0]["local"]:
+            want = (r[0]["local"][n] + r[1]["local"][n]) / 2
+            assert torch.allclose(r[0]["mean"][n], want, rtol=1e-6, atol=1e-8), n
+            assert torch.equal(r[0]["mean"][n], r[1]["mean"][n]), n
+            assert not torch.equal(r[0]["local"][n], r[1]["local"][n]), n   # the shards really differed

@@ -200,3 +200,59 @@ class DataParallelTrainer:
         if step_optimizer:
             self.optimizer.step()
         return loss.detach()
+
+
+class GradAverager:
+    """Gradient averaging for a model whose backward pass hands over all gradients at once (LUNeXt, whose custom
+    autograd function returns them together): after loss.backward(), copy every gradient into a few large flat
+    fp32 buckets with a fixed layout, all-reduce the buckets, copy the means back.  Parameters without a gradient
+    (LUNeXt's four unused att*.output_conv layers, lunext.py:74) occupy zeros in the buckets, so the layout never
+    depends on which gradients exist, and they are left without a gradient afterwards."""
+
+    def __init__(self, params, bucket_bytes=25 << 20, process_group=None):
+        self.params = [p for p in params if p.requires_grad]
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        dev = self.params[0].device
+        self.buckets = []                       # (flat tensor, [(param, view)])
+        cur, size = [], 0
+        for p in self.params:
+            cur.append(p)
+            size += p.numel()
+            if size * 4 >= bucket_bytes:
+                self._close(cur, size, dev)
+                cur, size = [], 0
+        if cur:
+            self._close(cur, size, dev)
+
+    def _close(self, plist, size, dev):
+        flat = torch.zeros(size, dtype=torch.float32, device=dev)
+        views, off = [], 0
+        for p in plist:
+            views.append((p, flat[off:off + p.numel()].view(p.shape)))
+            off += p.numel()
+        self.buckets.append((flat, views))
+
+    def broadcast_from_rank0(self, module):
+        if self.world > 1:
+            for t in list(module.parameters()) + list(module.buffers()):
+                dist.broadcast(t.data, src=0, group=self.group)
+
+    def average(self):
+        """In place: every existing p.grad becomes the mean over ranks."""
+        if self.world == 1:
+            return
+        works = []
+        for flat, views in self.buckets:
+            have = [(p, v) for p, v in views if p.grad is not None]
+            if len(have) != len(views):
+                flat.zero_()
+            if have:
+                torch._foreach_copy_([v for _, v in have], [p.grad for p, _ in have])
+            works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for (flat, views), w in zip(self.buckets, works):
+            w.wait()
+            flat.mul_(1.0 / self.world)
+            have = [(p, v) for p, v in views if p.grad is not None]
+            if have:
+                torch._foreach_copy_([p.grad for p, _ in have], [v for _, v in have])

@@ -215,14 +215,23 @@ def train_model(train_data, validation_data, model_type="UNet", epochs=50, batch
             for g in opt.param_groups:
                 g["lr"] = v
 
+        from .dp import GradAverager
+        joined = data_parallel and torch.distributed.is_initialized()
+        averager = GradAverager(model.parameters()) if joined else None
+        if averager is not None:
+            averager.broadcast_from_rank0(model)
+
         def train_step(images, masks):
             model.train()
             opt.zero_grad(set_to_none=True)
             loss = loss_fn(model(images), masks)
             loss.backward()
+            if averager is not None:
+                averager.average()              # mean of the per-shard gradients, as for the U-Net
             opt.step()
             return loss.detach()
-        rank, world = 0, 1
+        rank = torch.distributed.get_rank() if joined else 0
+        world = torch.distributed.get_world_size() if joined else 1
     scheduler = PlateauLR(get_lr, set_lr, patience=5, factor=0.5)
 
     n_train, n_val = len(x_tr), len(x_va)
