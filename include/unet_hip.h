@@ -216,12 +216,13 @@ int uh_gate_bwd(long long Mp, int C, const void* dout, int d_cstride, int d_coff
 /* out = a + b (+ c when c != null) */
 int uh_add(long long Mp, int C, const void* a, int a_cstride, int a_coff, const void* b, int b_cstride, int b_coff,
            const void* c, int c_cstride, int c_coff, void* out, int o_cstride, int o_coff, uh_stream s);
-/* fully fused gate for the 8-channel top level; wts = W1[8][8]|W2[8][8]|W3[8][8]|b1[8]|b2[8]|b3[8] fp32,
+/* fully fused gate for the 8-channel top level; wts = W1[8][8]|W2[8][8]|W3[8][8]|b1[8]|b2[8]|b3[8] fp32
+ * ([co][ci], zero beyond the c_real real channels; only those are computed),
  * partial[blk][216] (blk < uh_gate8_parts) holds the weight gradients in the same layout */
-int uh_gate8_fwd(long long Mp, const void* g, int g_cstride, int g_coff, const void* x, int x_cstride, int x_coff,
-                 const float* wts, const uint8_t* rowmask, void* out, int o_cstride, int o_coff, uh_stream s);
+int uh_gate8_fwd(long long Mp, int c_real, const void* g, int g_cstride, int g_coff, const void* x, int x_cstride,
+                 int x_coff, const float* wts, const uint8_t* rowmask, void* out, int o_cstride, int o_coff, uh_stream s);
 int uh_gate8_parts(long long Mp);
-int uh_gate8_bwd(long long Mp, const void* dout, int d_cstride, int d_coff, const void* g, int g_cstride, int g_coff,
+int uh_gate8_bwd(long long Mp, int c_real, const void* dout, int d_cstride, int d_coff, const void* g, int g_cstride, int g_coff,
                  const void* x, int x_cstride, int x_coff, const float* wts,
                  void* dg, int dg_cstride, int dg_coff, void* dx, int dx_cstride, int dx_coff,
                  float* partial, uh_stream s);

@@ -68,9 +68,9 @@ SIGNATURES = {
     "uh_gate_fwd": (I, [L, I, P, I, I, P, I, I, P, I, I, P]),
     "uh_gate_bwd": (I, [L, I, P, I, I, P, I, I, P, I, I, P, P, I, I, P, I, I, P]),
     "uh_add": (I, [L, I, P, I, I, P, I, I, P, I, I, P, I, I, P]),
-    "uh_gate8_fwd": (I, [L, P, I, I, P, I, I, P, P, P, I, I, P]),
+    "uh_gate8_fwd": (I, [L, I, P, I, I, P, I, I, P, P, P, I, I, P]),
     "uh_gate8_parts": (I, [L]),
-    "uh_gate8_bwd": (I, [L, P, I, I, P, I, I, P, I, I, P, P, I, I, P, I, I, P, P]),
+    "uh_gate8_bwd": (I, [L, I, P, I, I, P, I, I, P, I, I, P, P, I, I, P, I, I, P, P]),
     "uh_nchw_to_c8": (I, [I, I, I, I, P, P, I, I, P]),
     "uh_adam_step": (I, [L, P, P, P, P, F, F, F, F, F, I, P]),
     "uh_confusion_counts": (I, [I, L, P, P, P, P]),

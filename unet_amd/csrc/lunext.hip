@@ -590,6 +590,9 @@ extern "C" int uh_add(long long Mp, int C, const void* a, int a_cstride, int a_c
 // ---- the 8-channel gate of the top level, fully fused -------------------------------------------------------------------
 // wts: W1[8][8] | W2[8][8] | W3[8][8] | b1[8] | b2[8] | b3[8]   (fp32, [co][ci], zero padded beyond the real channels)
 #define G8_W 216
+// CR = real channels (the rest of the 8 are zero padding: zero activations, zero weights, so their terms vanish and
+// are not computed: at the 3-channel level that is 9 of 64 multiply-adds per matrix)
+template <int CR>
 __global__ __launch_bounds__(256) void gate8_fwd_kernel(long long Mp, const char* __restrict__ g, int g_cs, int g_co,
                                                         const char* __restrict__ x, int x_cs, int x_co,
                                                         const float* __restrict__ wts,
@@ -607,28 +610,44 @@ __global__ __launch_bounds__(256) void gate8_fwd_kernel(long long Mp, const char
     unpack8(*(const U4*)(g + (m * g_cs + g_co) * 2), gv);
     unpack8(*(const U4*)(x + (m * x_cs + x_co) * 2), xv);
 #pragma unroll
-    for (int co = 0; co < 8; ++co) {
+    for (int co = 0; co < 8; ++co) o[co] = 0.f;
+#pragma unroll
+    for (int co = 0; co < CR; ++co) {
       float z1 = w[192 + co], z2 = w[200 + co], z3 = w[208 + co];
 #pragma unroll
-      for (int ci = 0; ci < 8; ++ci) {
+      for (int ci = 0; ci < CR; ++ci) {
         z1 += w[co * 8 + ci] * gv[ci];
         z2 += w[64 + co * 8 + ci] * gv[ci];
         z3 += w[128 + co * 8 + ci] * (gv[ci] + xv[ci]);
       }
       o[co] = sigmoidf_(z3) * xv[co] + sigmoidf_(z1) * tanhf(z2);
     }
+    // (a padding channel: x = 0 kills the first term, and the second is sigmoid(b1)*tanh(b2) = 0.5*tanh(0) = 0)
     *(U4*)(out + (m * o_cs + o_co) * 2) = pack8(o);
   }
 }
 
-extern "C" int uh_gate8_fwd(long long Mp, const void* g, int g_cstride, int g_coff, const void* x, int x_cstride,
-                            int x_coff, const float* wts, const uint8_t* rowmask, void* out, int o_cstride,
-                            int o_coff, uh_stream s) {
+#define UH_GATE8_DISPATCH(c_real, LAUNCH) \
+  switch (c_real) {                       \
+    case 1: LAUNCH(1); break;             \
+    case 2: LAUNCH(2); break;             \
+    case 3: LAUNCH(3); break;             \
+    case 4: LAUNCH(4); break;             \
+    default: LAUNCH(8); break;            \
+  }
+
+extern "C" int uh_gate8_fwd(long long Mp, int c_real, const void* g, int g_cstride, int g_coff, const void* x,
+                            int x_cstride, int x_coff, const float* wts, const uint8_t* rowmask, void* out,
+                            int o_cstride, int o_coff, uh_stream s) {
   UH_REQUIRE(Mp > 0 && g && x && wts && rowmask && out, "gate8_fwd: bad arguments");
+  UH_REQUIRE(c_real >= 1 && c_real <= 8, "gate8_fwd: c_real=%d", c_real);
   long long blocks = (Mp + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(gate8_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, Mp, (const char*)g,
-                     g_cstride, g_coff, (const char*)x, x_cstride, x_coff, wts, rowmask, (char*)out, o_cstride, o_coff);
+#define UH_L(CR)                                                                                                       \
+  hipLaunchKernelGGL(gate8_fwd_kernel<CR>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, Mp, (const char*)g,    \
+                     g_cstride, g_coff, (const char*)x, x_cstride, x_coff, wts, rowmask, (char*)out, o_cstride, o_coff)
+  UH_GATE8_DISPATCH(c_real, UH_L)
+#undef UH_L
   return uh_check_launch("gate8_fwd");
 }
 
@@ -640,6 +659,7 @@ static inline int gate8_blocks(long long Mp) {
 extern "C" int uh_gate8_parts(long long Mp) { return gate8_blocks(Mp); }
 
 // partial[blk][216] in the layout of wts: dW1 | dW2 | dW3 | db1 | db2 | db3
+template <int CR>
 __global__ __launch_bounds__(256) void gate8_bwd_kernel(long long Mp, const char* __restrict__ dout, int d_cs, int d_co,
                                                         const char* __restrict__ g, int g_cs, int g_co,
                                                         const char* __restrict__ x, int x_cs, int x_co,
@@ -649,22 +669,29 @@ __global__ __launch_bounds__(256) void gate8_bwd_kernel(long long Mp, const char
   __shared__ float w[G8_W];
   __shared__ float red[4][G8_W];
   for (int i = threadIdx.x; i < G8_W; i += 256) w[i] = wts[i];
+  for (int i = threadIdx.x; i < 4 * G8_W; i += 256) (&red[0][0])[i] = 0.f;     // entries of padding channels stay zero
   __syncthreads();
-  float acc[G8_W];
+  float aw[3][CR][CR], ab[3][CR];
 #pragma unroll
-  for (int i = 0; i < G8_W; ++i) acc[i] = 0.f;
+  for (int q = 0; q < 3; ++q)
+#pragma unroll
+    for (int co = 0; co < CR; ++co) {
+      ab[q][co] = 0.f;
+#pragma unroll
+      for (int ci = 0; ci < CR; ++ci) aw[q][co][ci] = 0.f;
+    }
   for (long long m = (long long)blockIdx.x * 256 + threadIdx.x; m < Mp; m += (long long)gridDim.x * 256) {
     float gv[8], xv[8], d[8], og[8], ox[8];
     unpack8(*(const U4*)(g + (m * g_cs + g_co) * 2), gv);
     unpack8(*(const U4*)(x + (m * x_cs + x_co) * 2), xv);
-    unpack8(*(const U4*)(dout + (m * d_cs + d_co) * 2), d);      // zero on pad rows
+    unpack8(*(const U4*)(dout + (m * d_cs + d_co) * 2), d);      // zero on pad rows and in padding channels
 #pragma unroll
     for (int ci = 0; ci < 8; ++ci) og[ci] = ox[ci] = 0.f;
 #pragma unroll
-    for (int co = 0; co < 8; ++co) {
+    for (int co = 0; co < CR; ++co) {
       float z1 = w[192 + co], z2 = w[200 + co], z3 = w[208 + co];
 #pragma unroll
-      for (int ci = 0; ci < 8; ++ci) {
+      for (int ci = 0; ci < CR; ++ci) {
         z1 += w[co * 8 + ci] * gv[ci];
         z2 += w[64 + co * 8 + ci] * gv[ci];
         z3 += w[128 + co * 8 + ci] * (gv[ci] + xv[ci]);
@@ -675,40 +702,51 @@ __global__ __launch_bounds__(256) void gate8_bwd_kernel(long long Mp, const char
       const float dz3 = d[co] * xv[co] * a * (1.f - a);
       ox[co] += d[co] * a;
 #pragma unroll
-      for (int ci = 0; ci < 8; ++ci) {
+      for (int ci = 0; ci < CR; ++ci) {
         const float t = w[128 + co * 8 + ci] * dz3;
         og[ci] += w[co * 8 + ci] * dz1 + w[64 + co * 8 + ci] * dz2 + t;
         ox[ci] += t;
-        acc[co * 8 + ci] += dz1 * gv[ci];
-        acc[64 + co * 8 + ci] += dz2 * gv[ci];
-        acc[128 + co * 8 + ci] += dz3 * (gv[ci] + xv[ci]);
+        aw[0][co][ci] += dz1 * gv[ci];
+        aw[1][co][ci] += dz2 * gv[ci];
+        aw[2][co][ci] += dz3 * (gv[ci] + xv[ci]);
       }
-      acc[192 + co] += dz1;
-      acc[200 + co] += dz2;
-      acc[208 + co] += dz3;
+      ab[0][co] += dz1;
+      ab[1][co] += dz2;
+      ab[2][co] += dz3;
     }
     *(U4*)(dg + (m * dg_cs + dg_co) * 2) = pack8(og);
     *(U4*)(dx + (m * dx_cs + dx_co) * 2) = pack8(ox);
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-  for (int i = 0; i < G8_W; ++i) {
-    const float v = wave_sum(acc[i]);
-    if (lane == 0) red[wave][i] = v;
-  }
+  for (int q = 0; q < 3; ++q)
+#pragma unroll
+    for (int co = 0; co < CR; ++co) {
+#pragma unroll
+      for (int ci = 0; ci < CR; ++ci) {
+        const float v = wave_sum(aw[q][co][ci]);
+        if (lane == 0) red[wave][64 * q + co * 8 + ci] = v;
+      }
+      const float v = wave_sum(ab[q][co]);
+      if (lane == 0) red[wave][192 + 8 * q + co] = v;
+    }
   __syncthreads();
   for (int i = threadIdx.x; i < G8_W; i += 256)
     partial[(long long)blockIdx.x * G8_W + i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
 }
 
-extern "C" int uh_gate8_bwd(long long Mp, const void* dout, int d_cstride, int d_coff, const void* g, int g_cstride,
-                            int g_coff, const void* x, int x_cstride, int x_coff, const float* wts, void* dg,
-                            int dg_cstride, int dg_coff, void* dx, int dx_cstride, int dx_coff, float* partial,
+extern "C" int uh_gate8_bwd(long long Mp, int c_real, const void* dout, int d_cstride, int d_coff, const void* g,
+                            int g_cstride, int g_coff, const void* x, int x_cstride, int x_coff, const float* wts,
+                            void* dg, int dg_cstride, int dg_coff, void* dx, int dx_cstride, int dx_coff, float* partial,
                             uh_stream s) {
   UH_REQUIRE(Mp > 0 && dout && g && x && wts && dg && dx && partial, "gate8_bwd: bad arguments");
-  hipLaunchKernelGGL(gate8_bwd_kernel, dim3(gate8_blocks(Mp)), dim3(256), 0, (hipStream_t)s, Mp, (const char*)dout,
-                     d_cstride, d_coff, (const char*)g, g_cstride, g_coff, (const char*)x, x_cstride, x_coff, wts,
-                     (char*)dg, dg_cstride, dg_coff, (char*)dx, dx_cstride, dx_coff, partial);
+  UH_REQUIRE(c_real >= 1 && c_real <= 8, "gate8_bwd: c_real=%d", c_real);
+#define UH_L(CR)                                                                                                        \
+  hipLaunchKernelGGL(gate8_bwd_kernel<CR>, dim3(gate8_blocks(Mp)), dim3(256), 0, (hipStream_t)s, Mp, (const char*)dout,  \
+                     d_cstride, d_coff, (const char*)g, g_cstride, g_coff, (const char*)x, x_cstride, x_coff, wts,      \
+                     (char*)dg, dg_cstride, dg_coff, (char*)dx, dx_cstride, dx_coff, partial)
+  UH_GATE8_DISPATCH(c_real, UH_L)
+#undef UH_L
   return uh_check_launch("gate8_bwd");
 }
 

@@ -259,7 +259,7 @@ class LUNeXtRun:
             for j, conv in enumerate((att.sigmoid_conv, att.tanh_conv, att.combine_conv)):
                 wts[64 * j:64 * j + 64].view(8, 8)[:C, :C] = conv.weight.detach().view(C, C)
                 wts[192 + 8 * j:192 + 8 * j + C] = conv.bias.detach()
-            call("uh_gate8_fwd", g.Mp, g.ptr, g.cstride, g.coff, x.ptr, x.cstride, x.coff, wts.data_ptr(),
+            call("uh_gate8_fwd", g.Mp, C, g.ptr, g.cstride, g.coff, x.ptr, x.cstride, x.coff, wts.data_ptr(),
                  self.masks[l].data_ptr(), out.ptr, out.cstride, out.coff, s)
             self.saved[f"att{k}"] = (g, x, wts)
             return out
@@ -295,7 +295,7 @@ class LUNeXtRun:
             dg, dx = Ls.act(B, H, W, 8), Ls.act(B, H, W, 8)
             parts = L.uh_gate8_parts(g.Mp)
             part = Ls.f32(parts * 216)
-            call("uh_gate8_bwd", g.Mp, dout.ptr, dout.cstride, dout.coff, g.ptr, g.cstride, g.coff, x.ptr, x.cstride,
+            call("uh_gate8_bwd", g.Mp, C, dout.ptr, dout.cstride, dout.coff, g.ptr, g.cstride, g.coff, x.ptr, x.cstride,
                  x.coff, wts.data_ptr(), dg.ptr, dg.cstride, dg.coff, dx.ptr, dx.cstride, dx.coff, part.data_ptr(), s)
             gw = Ls.f32(216)
             call("uh_colsum_finalize", part.data_ptr(), parts, 216, 1, gw.data_ptr(), 0, s)
