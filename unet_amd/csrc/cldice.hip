@@ -259,6 +259,30 @@ __global__ __launch_bounds__(256) void skel_bwd_level_kernel(BwdArgs a) {
   const float* ek1 = a.ek1 + plane;
   const float gout = *a.gout;
 
+  // Everything this workgroup reads from global memory is requested up front: the per-position operands of stages
+  // A and B go into registers now, so no stage waits for a load in the middle of its loop (with four workgroups
+  // per CU those exposed latencies, not instructions or bandwidth, set the kernel's time).
+  constexpr int KA = (N2 * N2 + 255) / 256, KB = (N1 * N1 + 255) / 256;
+  float pre_gs[KA], pre_sp[KA], pre_g1[KB];
+#pragma unroll
+  for (int k = 0; k < KA; ++k) {
+    const int i = tid + 256 * k;
+    const int y = y0 - 2 + i / N2, x = x0 - 2 + i % N2;
+    pre_gs[k] = 0.f;
+    pre_sp[k] = 0.f;
+    if (i < N2 * N2 && g.in(y, x)) {
+      const long long gi = plane + (long long)y * a.W + x;
+      pre_gs[k] = a.top ? a.yt[gi] : a.gs_in[gi];
+      if (a.skel_prev) pre_sp[k] = a.skel_prev[gi];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < KB; ++k) {
+    const int i = tid + 256 * k;
+    const int y = y0 - 1 + i / N1, x = x0 - 1 + i % N1;
+    pre_g1[k] = (a.ge1_in && i < N1 * N1 && g.in(y, x)) ? a.ge1_in[plane + (long long)y * a.W + x] : 0.f;
+  }
+  const float c4 = a.top ? a.coef[4] : 0.f, c5 = a.top ? a.coef[5] : 0.f;
   for (int i = tid; i < N3 * N3; i += 256) {
     const int y = y0 - 3 + i / N3, x = x0 - 3 + i % N3;
     sE1[i] = g.in(y, x) ? ek1[y * a.W + x] : -INFINITY;
@@ -275,36 +299,35 @@ __global__ __launch_bounds__(256) void skel_bwd_level_kernel(BwdArgs a) {
   __syncthreads();
 
   // stage A: pointwise on core+2
-  for (int i = tid; i < N2 * N2; i += 256) {
+#pragma unroll
+  for (int k = 0; k < KA; ++k) {
+    const int i = tid + 256 * k;
+    if (i >= N2 * N2) break;
     const int ly = i / N2, lx = i % N2;
     const int y = y0 - 2 + ly, x = x0 - 2 + lx;
     float gd = 0.f;
     int am = -1;
     if (g.in(y, x)) {
       // 3x3 window of E_{k+1} in row-major order, first maximum wins
+      float win[9];                     // all nine reads first: one LDS round trip instead of nine
+#pragma unroll
+      for (int t = 0; t < 9; ++t) win[t] = sE1[(ly + t / 3) * N3 + lx + t % 3];
       float best = -INFINITY;
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
-        const float v = sE1[(ly + t / 3) * N3 + lx + t % 3];
-        if (v > best) {
-          best = v;
-          am = t;
-        }
+        const bool up = win[t] > best;
+        best = up ? win[t] : best;
+        am = up ? t : am;
       }
       const float e = sE[i];
       const float diff = e - best;
       const float delta = fmaxf(diff, 0.f);
       const long long gi = plane + (long long)y * a.W + x;
-      float gs;
-      if (a.top) {
-        gs = gout * (a.coef[4] * clamp01(a.yt[gi]) + a.coef[5]);
-      } else {
-        gs = a.gs_in[gi];
-      }
+      const float gs = a.top ? gout * (c4 * clamp01(pre_gs[k]) + c5) : pre_gs[k];
       float gdelta = gs;
       const bool core = (ly >= 2 && ly < 2 + BT && lx >= 2 && lx < 2 + BT);
       if (a.skel_prev) {
-        const float sp = a.skel_prev[gi];
+        const float sp = pre_sp[k];
         const float prod = sp * delta;
         const bool on = (delta - prod) > 0.f;
         gdelta = on ? gs * (1.f - sp) : 0.f;
@@ -322,21 +345,28 @@ __global__ __launch_bounds__(256) void skel_bwd_level_kernel(BwdArgs a) {
   // stage B on core+1: complete dL/dE_{k+1}(q) = incoming part + the dilation windows whose arg-max is q, and how
   // window q of the erosion E_{k+1} = erode(E_k) routes it: min(vertical min, horizontal min), torch.min splits a tie
   // 1/2 : 1/2, inside each 3-window the FIRST minimum (top/left, centre, bottom/right) takes the gradient
-  for (int i = tid; i < N1 * N1; i += 256) {
+#pragma unroll
+  for (int k = 0; k < KB; ++k) {
+    const int i = tid + 256 * k;
+    if (i >= N1 * N1) break;
     const int ly = i / N1, lx = i % N1;
     const int y = y0 - 1 + ly, x = x0 - 1 + lx;
     float gv = 0.f, gh = 0.f;
     int code = 15;
     if (g.in(y, x)) {
-      float v = a.ge1_in ? a.ge1_in[plane + (long long)y * a.W + x] : 0.f;
+      float v = pre_g1[k];
+      // window centred at q + (dy,dx), t = (dy+1)*3 + (dx+1): q sits at slot 8 - t of that window.  All reads
+      // first, then selects (adding 0 where the arg-max is elsewhere leaves the sum unchanged)
+      float gdw[9];
+      int amw[9];
 #pragma unroll
-      for (int dy = -1; dy <= 1; ++dy)
+      for (int t = 0; t < 9; ++t) {
+        const int qi = (ly + t / 3) * N2 + lx + t % 3;
+        gdw[t] = sGD[qi];
+        amw[t] = sAM[qi];
+      }
 #pragma unroll
-        for (int dx = -1; dx <= 1; ++dx) {
-          // window centred at q + (dy,dx); q sits at slot (-dy+1)*3 + (-dx+1) of that window
-          const int qi = (ly + 1 + dy) * N2 + lx + 1 + dx;
-          if (sAM[qi] == (1 - dy) * 3 + (1 - dx)) v += sGD[qi];
-        }
+      for (int t = 0; t < 9; ++t) v += (amw[t] == 8 - t) ? gdw[t] : 0.f;
       const int ci = (ly + 1) * N2 + lx + 1;               // q in sE coordinates
       const float c = sE[ci];
       float vmin = sE[ci - N2];
