@@ -264,63 +264,87 @@ struct BandCfg {
 template <int BM, int BN, int MODE>
 __device__ __forceinline__ void band_epilogue(const GemmArgs& p, const f32x4 (&acc)[4][4], int mt, int nt,
                                               const uint32_t (&fw)[4], int wm, int wn, int l15, int g, float* red) {
+  // While a workgroup is here none of its waves issues MFMAs, and at K = 64 this is a quarter of a tile's life,
+  // so the arithmetic is laid out for the packed fp32 instructions: values are handled as PAIRS OF ROWS (e, e+1),
+  // which are adjacent registers of one accumulator, so no register moves are needed to form the operands.
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
   const int ncol = wn * 64 + l15 * 4;
   const int n0 = nt * BN;
-  float cb[4] = {0.f, 0.f, 0.f, 0.f}, csc[4] = {1.f, 1.f, 1.f, 1.f};
+  f32x2 cb[4], csc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { cb[j] = f32x2{0.f, 0.f}; csc[j] = f32x2{1.f, 1.f}; }
   if (MODE == UH_EPI_AFFINE_RELU) {
     const f32x4 a4 = *(const f32x4*)(p.scale + n0 + ncol), b4 = *(const f32x4*)(p.shift + n0 + ncol);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { csc[j] = a4[j]; cb[j] = b4[j]; }
+    for (int j = 0; j < 4; ++j) { csc[j] = f32x2{a4[j], a4[j]}; cb[j] = f32x2{b4[j], b4[j]}; }
   } else if (p.bias) {
     const f32x4 b4 = *(const f32x4*)(p.bias + n0 + ncol);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) cb[j] = b4[j];
+    for (int j = 0; j < 4; ++j) cb[j] = f32x2{b4[j], b4[j]};
   }
   const long long mrow0 = (long long)mt * BM + wm * 64 + g * 4;
   char* orow = p.out + ((mrow0 * p.o_cstride) + p.o_coff + n0 + ncol) * 2;
   const long long o_row_bytes = (long long)p.o_cstride * 2;
-  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool ragged = (long long)(mt + 1) * BM > p.Mp;      // only the last M tile has rows past the end
+  f32x2 s1[4], s2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { s1[j] = f32x2{0.f, 0.f}; s2[j] = f32x2{0.f, 0.f}; }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
+    uint32_t fl = fw[i];
+    if (ragged) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const long long m = mrow0 + i * 16 + e;
-      const float f = (m < p.Mp) ? (float)((fw[i] >> (8 * e)) & 0xffu) : 0.f;
-      float v[4];
+      for (int e = 0; e < 4; ++e)
+        if (mrow0 + i * 16 + e >= p.Mp) fl &= ~(0xffu << (8 * e));
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                            // rows e = 2h, 2h + 1
+      const f32x2 f = f32x2{(float)((fl >> (16 * h)) & 0xffu), (float)((fl >> (16 * h + 8)) & 0xffu)};
+      f32x2 v[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float x = acc[i][j][e];
-        if (MODE == UH_EPI_AFFINE_RELU) x = fmaxf(x * csc[j] + cb[j], 0.f);
-        else x += cb[j];
-        x *= f;
+        f32x2 x = f32x2{acc[i][j][2 * h], acc[i][j][2 * h + 1]};
+        if (MODE == UH_EPI_AFFINE_RELU) {
+          x = x * csc[j] + cb[j];
+          x = f32x2{fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)};
+        } else {
+          x = x + cb[j];
+        }
+        x = x * f;
         if (MODE == UH_EPI_RAW_STATS) {
-          s1[j] += x;
-          s2[j] += x * x;
+          s1[j] = s1[j] + x;
+          s2[j] = x * x + s2[j];
         }
         v[j] = x;
       }
-      uint2 o;
-      if (MODE == UH_EPI_RAW_STATS) {
-        o.x = pack2h(v[0], v[1]);
-        o.y = pack2h(v[2], v[3]);
-      } else {
-        o.x = pack2(v[0], v[1]);
-        o.y = pack2(v[2], v[3]);
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        uint2 o;
+        if (MODE == UH_EPI_RAW_STATS) {
+          o.x = pack2h(v[0][r], v[1][r]);
+          o.y = pack2h(v[2][r], v[3][r]);
+        } else {
+          o.x = pack2(v[0][r], v[1][r]);
+          o.y = pack2(v[2][r], v[3][r]);
+        }
+        *(uint2*)(orow + (i * 16 + 2 * h + r) * o_row_bytes) = o;
       }
-      *(uint2*)(orow + (i * 16 + e) * o_row_bytes) = o;
     }
   }
   if (MODE == UH_EPI_RAW_STATS) {
+    float t1[4], t2[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      s1[j] += __shfl_xor(s1[j], 16, 64);
-      s1[j] += __shfl_xor(s1[j], 32, 64);
-      s2[j] += __shfl_xor(s2[j], 16, 64);
-      s2[j] += __shfl_xor(s2[j], 32, 64);
+      t1[j] = s1[j][0] + s1[j][1];
+      t2[j] = s2[j][0] + s2[j][1];
+      t1[j] += __shfl_xor(t1[j], 16, 64);
+      t1[j] += __shfl_xor(t1[j], 32, 64);
+      t2[j] += __shfl_xor(t2[j], 16, 64);
+      t2[j] += __shfl_xor(t2[j], 32, 64);
     }
     if (g == 0) {
-      *(f32x4*)(red + (wm * 2 + 0) * BN + ncol) = f32x4{s1[0], s1[1], s1[2], s1[3]};
-      *(f32x4*)(red + (wm * 2 + 1) * BN + ncol) = f32x4{s2[0], s2[1], s2[2], s2[3]};
+      *(f32x4*)(red + (wm * 2 + 0) * BN + ncol) = f32x4{t1[0], t1[1], t1[2], t1[3]};
+      *(f32x4*)(red + (wm * 2 + 1) * BN + ncol) = f32x4{t2[0], t2[1], t2[2], t2[3]};
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // raw barriers do not wait for LDS writes
   }
