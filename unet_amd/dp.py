@@ -155,6 +155,7 @@ class DataParallelTrainer:
         self.buckets = GradBuckets(model, bucket_bytes)
         self.optimizer = FlatAdam(model, self.buckets, lr=lr)                      # training_utils.py:107
         self.timer = None
+        self._run = None
         # UNET_AMD_FORCE_COLLECTIVES=1 runs the broadcasts and all-reduces with a single rank too (a rehearsal
         # of the RCCL calls on a one-GPU machine)
         self.collectives = joined and (self.world > 1 or os.environ.get("UNET_AMD_FORCE_COLLECTIVES") == "1")
@@ -178,6 +179,8 @@ class DataParallelTrainer:
             b = self.buckets.buckets[i]
             b["pending"].discard(n)
             if not b["pending"] and self.collectives and "work" not in b:
+                if self._run is not None:
+                    self._run.join_side_stream()         # gradients written on the engine's second stream
                 b["work"] = dist.all_reduce(b["tensor"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def train_step(self, images, masks, step_optimizer=True):
@@ -185,7 +188,7 @@ class DataParallelTrainer:
         model = self.model
         model.train()
         self.buckets.reset()
-        run = UNetRun(model, images.float().contiguous(), training=True)
+        run = self._run = UNetRun(model, images.float().contiguous(), training=True)
         run.timer = self.timer
         logits = run.forward().requires_grad_(True)
         loss = self.criterion(logits, masks)
@@ -193,6 +196,7 @@ class DataParallelTrainer:
         (dlogits,) = torch.autograd.grad(loss / self.world, logits)
         run.backward(dlogits, grad_alloc=lambda n, shape: self.buckets.views[n], on_ready=self._on_ready)
         run.release()
+        self._run = None
         for b in self.buckets.buckets:
             w = b.pop("work", None)
             if w is not None:
