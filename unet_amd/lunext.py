@@ -10,12 +10,15 @@ fused vector kernel at the 8-channel level; GEMM operands narrower than 64 are z
 `att*.output_conv` is declared but never called by the reference (lunext.py:74,120): its parameters
 exist in the state_dict and receive no gradient, as there.
 """
+import contextlib
+import os
+
 import torch
 import torch.nn as nn
 
 from . import _lib
 from ._lib import call, EPI_RAW_STATS, EPI_AFFINE_RELU, EPI_MASKED, EPI_CONVT
-from .engine import BN_EPS, BN_MOMENTUM, _stream
+from .engine import BN_EPS, BN_MOMENTUM, _stream, _SIDE_STREAMS
 from .layout import pool_for
 
 L = _lib.lib
@@ -56,6 +59,8 @@ class LUNeXtRun:
         self.cp = [_padc(c) for c in self.chans]
         self.recs = {}
         self.saved = {}
+        self._deferred = []                      # (gradient name, closure) to run once the second stream is joined
+        self._side_used = None
 
     # ------------------------------------------------------------------ depthwise block
     def _dw(self, name, x, lvl):
@@ -130,10 +135,12 @@ class LUNeXtRun:
              dr.coff, s)
         wparts = L.uh_dw_parts(B, H, W, Cp)
         wp = Ls.f32(wparts * 9 * Cp)
-        call("uh_dwconv3x3_wgrad", B, H, W, Cp, dy.ptr, dy.cstride, dy.coff, x.ptr, x.cstride, x.coff, wp.data_ptr(), s)
         w9g = Ls.f32(9 * Cp)
-        call("uh_colsum_finalize", wp.data_ptr(), wparts, 9 * Cp, 1, w9g.data_ptr(), 0, s)
-        grads[name + ".depthwise.weight"] = w9g.view(9, Cp)[:, :C].t().reshape(C, 1, 3, 3).contiguous()
+        with self._side() as s2:                     # beside the input gradient below: both only read dy and x
+            call("uh_dwconv3x3_wgrad", B, H, W, Cp, dy.ptr, dy.cstride, dy.coff, x.ptr, x.cstride, x.coff, wp.data_ptr(), s2)
+            call("uh_colsum_finalize", wp.data_ptr(), wparts, 9 * Cp, 1, w9g.data_ptr(), 0, s2)
+        self._deferred.append((name + ".depthwise.weight",
+                               lambda: w9g.view(9, Cp)[:, :C].t().reshape(C, 1, 3, 3).contiguous()))
         # conv bias in front of train-mode BatchNorm: exactly zero gradient
         grads[name + ".depthwise.bias"] = self._zeros(C)
         dx = Ls.act(B, H, W, Cp)
@@ -168,11 +175,12 @@ class LUNeXtRun:
         grads[f"downconv{l}.bias"] = self._colsum(dy, cout)
         S = L.uh_conv_wgrad_splits(Bs, Hs, Ws, cout, K, 1)
         part = Ls.f32(S * cout * K)
-        call("uh_conv_wgrad", Bs, Hs, Ws, dy.ptr, dy.cstride, dy.coff, cout, x4.ptr, x4.cstride, 0, K, 1,
-             part.data_ptr(), s)
         dw = torch.empty_like(conv.weight)
-        call("uh_wgrad_reduce_strided", part.data_ptr(), S, cout * K, cout, 4, cin, K, cpi, cin * 4, 1, 4,
-             dw.data_ptr(), 0, s)
+        with self._side() as s2:
+            call("uh_conv_wgrad", Bs, Hs, Ws, dy.ptr, dy.cstride, dy.coff, cout, x4.ptr, x4.cstride, 0, K, 1,
+                 part.data_ptr(), s2)
+            call("uh_wgrad_reduce_strided", part.data_ptr(), S, cout * K, cout, 4, cin, K, cpi, cin * 4, 1, 4,
+                 dw.data_ptr(), 0, s2)
         grads[f"downconv{l}.weight"] = dw
         # dx4[m][t*cpi + ci] = sum_co dy[m][co] * W[co][ci][t]
         wd = Ls.bf16_flat(K * cout, tag=f"down{l}.wd")
@@ -215,10 +223,11 @@ class LUNeXtRun:
         call("uh_space_to_depth2", Bs, Hs, Ws, cpo, dup.ptr, dup.cstride, dup.coff, d4.ptr, d4.cstride, 0, s)
         S = L.uh_conv_wgrad_splits(Bs, Hs, Ws, N, cin, 1)
         part = Ls.f32(S * N * cin)
-        call("uh_conv_wgrad", Bs, Hs, Ws, d4.ptr, d4.cstride, 0, N, x.ptr, x.cstride, x.coff, cin, 1, part.data_ptr(), s)
         dw = torch.empty_like(up.weight)                       # [cin][cout][2][2]
-        call("uh_wgrad_reduce_strided", part.data_ptr(), S, N * cin, cout, 4, cin, cin, cpo * cin, 4, 1, cout * 4,
-             dw.data_ptr(), 0, s)
+        with self._side() as s2:
+            call("uh_conv_wgrad", Bs, Hs, Ws, d4.ptr, d4.cstride, 0, N, x.ptr, x.cstride, x.coff, cin, 1, part.data_ptr(), s2)
+            call("uh_wgrad_reduce_strided", part.data_ptr(), S, N * cin, cout, 4, cin, cin, cpo * cin, 4, 1, cout * 4,
+                 dw.data_ptr(), 0, s2)
         grads[f"upconv{k}.weight"] = dw
         wd = Ls.bf16_flat(cin * N, tag=f"up{k}.wd")
         call("uh_pack_weights", up.weight.data_ptr(), wd.data_ptr(), cin, 4, cout, cout * 4, 1, 4, N, cpo, 0, s)
@@ -226,6 +235,24 @@ class LUNeXtRun:
         call("uh_conv_gemm", Bs, Hs, Ws, d4.ptr, d4.cstride, 0, N, wd.data_ptr(), cin, 1, EPI_MASKED, dx.ptr,
              dx.cstride, dx.coff, None, None, None, None, self.masks[l + 1].data_ptr(), s)
         return dx
+
+    @contextlib.contextmanager
+    def _side(self):
+        """Kernels launched inside run on a second stream, ordered after everything issued so far on the current one
+        (UNET_AMD_WGRAD_STREAM=0: on the current stream).  Only launches into buffers that already exist belong here:
+        memory that torch allocates while another stream is current is recycled on that stream's schedule.
+        backward() joins the stream before it returns."""
+        if os.environ.get("UNET_AMD_WGRAD_STREAM", "1") == "0":
+            yield _stream()
+            return
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        st = _SIDE_STREAMS.get(idx)
+        if st is None:
+            st = _SIDE_STREAMS[idx] = torch.cuda.Stream(device=self.device)
+        self._side_used = st
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            yield st.cuda_stream
 
     def _zeros(self, n):
         """n zeros out of one per-run buffer (gradients that are identically zero; nothing writes to them)."""
@@ -408,6 +435,11 @@ class LUNeXtRun:
             call("uh_add", tot.Mp, C, dpool.ptr, dpool.cstride, dpool.coff, sg.ptr, sg.cstride, sg.coff, None, 0, 0,
                  tot.ptr, tot.cstride, tot.coff, s)
             da = self._dw_backward(f"conv{l}_1", self._dw_backward(f"conv{l}_2", tot, grads), grads)
+        if self._side_used is not None:
+            torch.cuda.current_stream().wait_stream(self._side_used)
+        for n, make in self._deferred:
+            grads[n] = make()
+        self._deferred = []
         return grads
 
     def release(self):
