@@ -62,6 +62,13 @@ class UNetRun:
         self._ws, self._ws_bytes = None, 0
         self.packer = packer_for(module, x.device)
         self.wf = self.packer.get("fwd", _stream())       # packed forward operands, by layer name
+        if training:
+            # the operands of the input gradients are not needed before the backward pass: repack them beside the
+            # forward pass (the second stream first waits for the optimizer step that changed the weights)
+            side = self._side_stream()
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream())
+                self.packer.get("bwd", side.cuda_stream)
 
     # ------------------------------------------------------------------ helpers
     def _gemm(self, *args):
@@ -308,6 +315,7 @@ class UNetRun:
             raise RuntimeError("backward through an eval-mode (running-statistics) forward is not built; "
                                "call model.train() before a forward pass that needs gradients")
         m, L, s = self.m, self.lease, _stream()
+        self.join_side_stream()                            # the repack issued beside the forward pass
         self.wb = self.packer.get("bwd", s)                # rotated / transposed operands of the input gradients
         grads = {}
         dl = dlogits.contiguous().float()
@@ -342,9 +350,14 @@ class UNetRun:
             # bias gradient of the transposed conv: column sums of its output gradient
             parts = _lib.lib.uh_colsum_parts(dup.Mp, w)
             cp = L.f32(parts * w)
-            call("uh_colsum", dup.Mp, w, dup.ptr, dup.cstride, dup.coff, cp.data_ptr(), s)
             db = self._galloc(f"upconv{k}.bias", (w,))
-            call("uh_colsum_finalize", cp.data_ptr(), parts, w, 1, db.data_ptr(), 0, s)
+            side = self._side_stream()
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream())
+            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                sw = side.cuda_stream if side is not None else s
+                call("uh_colsum", dup.Mp, w, dup.ptr, dup.cstride, dup.coff, cp.data_ptr(), sw)
+                call("uh_colsum_finalize", cp.data_ptr(), parts, w, 1, db.data_ptr(), 0, sw)
             grads[f"upconv{k}.bias"] = db
             # gather the 2x2 output positions of every input position: d4[m][t*w + co]
             Bs, Hs, Ws = self.geo[l + 1]
