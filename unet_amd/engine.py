@@ -61,14 +61,19 @@ class UNetRun:
         self.timer = None          # optional KernelTimer (bench): times selected kernel launches with events
         self._ws, self._ws_bytes = None, 0
         self.packer = packer_for(module, x.device)
-        self.wf = self.packer.get("fwd", _stream())       # packed forward operands, by layer name
-        if training:
-            # the operands of the input gradients are not needed before the backward pass: repack them beside the
-            # forward pass (the second stream first waits for the optimizer step that changed the weights)
-            side = self._side_stream()
-            if side is not None:
-                side.wait_stream(torch.cuda.current_stream())
-                self.packer.get("bwd", side.cuda_stream)
+        # Packed bf16 operands.  The first layer reads the fp32 weights themselves, so in training both repacks go to
+        # the second stream (which first waits for the optimizer step that changed the weights): the forward operands
+        # are awaited just before the second layer, the operands of the input gradients at the start of backward.
+        side = self._side_stream() if training else None
+        self._wf_ready = None
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
+            self.wf = self.packer.get("fwd", side.cuda_stream)
+            self._wf_ready = torch.cuda.Event()
+            self._wf_ready.record(side)
+            self.packer.get("bwd", side.cuda_stream)
+        else:
+            self.wf = self.packer.get("fwd", _stream())   # by layer name
 
     # ------------------------------------------------------------------ helpers
     def _gemm(self, *args):
@@ -147,6 +152,9 @@ class UNetRun:
                      conv.bias.data_ptr(), EPI_RAW_STATS, None, None, rec.y.ptr, rec.y.cstride, rec.y.coff,
                      stat.data_ptr(), s)
             else:
+                if self._wf_ready is not None:
+                    torch.cuda.current_stream().wait_event(self._wf_ready)
+                    self._wf_ready = None
                 wp = self.wf[name]
                 parts = _lib.lib.uh_conv_gemm_mtiles(B, H, W, cout)
                 stat = self.lease.f32(parts * 2 * cout)
