@@ -156,6 +156,7 @@ class DataParallelTrainer:
         self.optimizer = FlatAdam(model, self.buckets, lr=lr)                      # training_utils.py:107
         self.timer = None
         self._run = None
+        self._zeroed = False
         # UNET_AMD_FORCE_COLLECTIVES=1 runs the broadcasts and all-reduces with a single rank too (a rehearsal
         # of the RCCL calls on a one-GPU machine)
         self.collectives = joined and (self.world > 1 or os.environ.get("UNET_AMD_FORCE_COLLECTIVES") == "1")
@@ -190,6 +191,8 @@ class DataParallelTrainer:
         self.buckets.reset()
         run = self._run = UNetRun(model, images.float().contiguous(), training=True)
         run.timer = self.timer
+        run.zero_grads_kept = self._zeroed          # bucket memory: zero since the first step, summed with zeros since
+        self._zeroed = True
         logits = run.forward().requires_grad_(True)
         loss = self.criterion(logits, masks)
         # d(mean over ranks of loss)/dlogits: fold the 1/world of gradient averaging into the seed

@@ -58,6 +58,9 @@ class UNetRun:
         self.geo = [(B, H >> l, W >> l) for l in range(5)]
         self.masks = [self.pool.rowmask(*g) for g in self.geo]
         self.grad_alloc = self.on_ready = None
+        # set by a caller whose grad_alloc hands out the same memory every step and never writes to it: the gradients
+        # that are identically zero (conv biases in front of train-mode BatchNorm) then need no fill after the first step
+        self.zero_grads_kept = False
         self.timer = None          # optional KernelTimer (bench): times selected kernel launches with events
         self._ws, self._ws_bytes = None, 0
         self.packer = packer_for(module, x.device)
@@ -236,7 +239,7 @@ class UNetRun:
         in data-parallel training) or a fresh tensor."""
         if self.grad_alloc is not None:
             t = self.grad_alloc(name, shape)
-            if zero:
+            if zero and not self.zero_grads_kept:
                 t.zero_()
             return t
         f = torch.zeros if zero else torch.empty
