@@ -275,3 +275,28 @@ def test_module_surface():
     b = model(x * 0.5)
     (a.sum() + b.sum()).backward()
     assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+def test_two_stream_step_equals_one_stream_step(monkeypatch):
+    """The data-parallel trainer's step with the second stream (weight gradients, operand repacks, bucket-wise Adam
+    beside backward) against the same step with everything on one stream and one Adam launch at the end: only the
+    order of independent launches differs, so losses and parameters are bit-identical after several steps."""
+    from unet_amd.dp import DataParallelTrainer
+    x, m = ref_cpu.synth_batch(4, 3, 64, 64)
+    x, m = x.to(DEV), m.to(DEV)
+    results = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("UNET_AMD_WGRAD_STREAM", mode)
+        torch.manual_seed(11)
+        model = unet_amd.UNet(3, 1).to(DEV)
+        tr = DataParallelTrainer(model, lr=1e-3, bucket_bytes=8 << 20)      # several buckets
+        assert len(tr.buckets.buckets) >= 4
+        losses = [tr.train_step(x, m).item() for _ in range(4)]
+        torch.cuda.synchronize()
+        results[mode] = (losses, tr.optimizer.p.clone(), tr.optimizer.m.clone(), tr.optimizer.v.clone(), tr.optimizer.steps)
+    a, b = results["0"], results["1"]
+    assert a[0] == b[0], (a[0], b[0])
+    assert a[4] == b[4] == 4
+    for u, v in zip(a[1:4], b[1:4]):
+        assert torch.equal(u, v)
+    assert a[0][-1] < a[0][0]                      # and it trains

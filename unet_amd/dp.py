@@ -94,13 +94,15 @@ class GradBuckets:
 
     def _close(self, start, end, names):
         idx = len(self.buckets)
-        self.buckets.append(dict(tensor=self.flat[start:end], names=list(names), pending=set(names)))
+        self.buckets.append(dict(tensor=self.flat[start:end], names=list(names), pending=set(names), start=start, end=end))
         for n in names:
             self.bucket_of[n] = idx
 
     def reset(self):
         for b in self.buckets:
             b["pending"] = set(b["names"])
+            b.pop("launched", None)
+            b.pop("adam", None)
 
 
 class FlatAdam:
@@ -126,10 +128,22 @@ class FlatAdam:
                 off += q.numel()
 
     def step(self):
+        self.begin_step()
+        self.step_range(0, self.p.numel(), torch.cuda.current_stream(self.p.device).cuda_stream)
+        self.finish_step()
+
+    # the same step in pieces (a bucket at a time, as its gradients arrive): begin_step, step_range..., finish_step
+    def begin_step(self):
         self.steps += 1
-        _lib.call("uh_adam_step", self.p.numel(), self.p.data_ptr(), self.g.data_ptr(), self.m.data_ptr(),
-                  self.v.data_ptr(), self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.steps,
-                  torch.cuda.current_stream(self.p.device).cuda_stream)
+
+    def step_range(self, lo, hi, stream):
+        """elements [lo, hi) of the flat buffers; lo and hi multiples of 4"""
+        if hi > lo:
+            _lib.call("uh_adam_step", hi - lo, self.p.data_ptr() + 4 * lo, self.g.data_ptr() + 4 * lo,
+                      self.m.data_ptr() + 4 * lo, self.v.data_ptr() + 4 * lo, self.lr, self.betas[0], self.betas[1],
+                      self.eps, self.weight_decay, self.steps, stream)
+
+    def finish_step(self):
         # the kernel wrote through raw pointers: autograd's version counters did not move, and the packed bf16
         # operands key on them
         pk = getattr(self.model, "_packer", None)
@@ -157,6 +171,7 @@ class DataParallelTrainer:
         self.timer = None
         self._run = None
         self._zeroed = False
+        self._eager, self._adam_begun = True, False
         # UNET_AMD_FORCE_COLLECTIVES=1 runs the broadcasts and all-reduces with a single rank too (a rehearsal
         # of the RCCL calls on a one-GPU machine)
         self.collectives = joined and (self.world > 1 or os.environ.get("UNET_AMD_FORCE_COLLECTIVES") == "1")
@@ -179,16 +194,42 @@ class DataParallelTrainer:
             i = self.buckets.bucket_of[n]
             b = self.buckets.buckets[i]
             b["pending"].discard(n)
-            if not b["pending"] and self.collectives and "work" not in b:
+            if b["pending"] or b.get("launched"):
+                continue
+            b["launched"] = True
+            if self.collectives:
                 if self._run is not None:
                     self._run.join_side_stream()         # gradients written on the engine's second stream
                 b["work"] = dist.all_reduce(b["tensor"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._adam_for_bucket(i, b)
+
+    def _adam_for_bucket(self, i, b):
+        """Adam for a bucket as soon as its (averaged) gradients exist, on the engine's second stream, beside the rest
+        of the backward pass.  Nothing that backward still has to run reads fp32 parameters whose gradients are
+        complete: input gradients use the bf16 operands packed before, BatchNorm backward its saved scale."""
+        side = self._run._side_stream() if (self._eager and self._run is not None) else None
+        if side is None:
+            return
+        last = i == len(self.buckets.buckets) - 1
+        lo = b["start"] & ~3                           # bucket boundaries are parameter boundaries: round both ends
+        hi = self.optimizer.p.numel() if last else (b["end"] & ~3)   # down; the 0-3 elements cut off go with the next
+        side.wait_stream(torch.cuda.current_stream())  # gradients written on this stream (BatchNorm, biases)
+        with torch.cuda.stream(side):
+            w = b.get("work")
+            if w is not None:
+                w.wait()                               # the second stream waits for the collective
+            if not self._adam_begun:
+                self.optimizer.begin_step()
+                self._adam_begun = True
+            self.optimizer.step_range(lo, hi, side.cuda_stream)
+        b["adam"] = True
 
     def train_step(self, images, masks, step_optimizer=True):
         """images [b,C,H,W] fp32, masks [b,1,H,W] on this rank's device.  Returns the local loss (0-dim tensor)."""
         model = self.model
         model.train()
         self.buckets.reset()
+        self._eager, self._adam_begun = step_optimizer, False
         run = self._run = UNetRun(model, images.float().contiguous(), training=True)
         run.timer = self.timer
         run.zero_grads_kept = self._zeroed          # bucket memory: zero since the first step, summed with zeros since
@@ -205,7 +246,12 @@ class DataParallelTrainer:
             if w is not None:
                 w.wait()                     # current stream waits for the collective
         if step_optimizer:
-            self.optimizer.step()
+            if self._adam_begun:                 # done bucket by bucket beside backward (joined at its end)
+                missing = [b for b in self.buckets.buckets if not b.get("adam")]
+                assert not missing, "a bucket never became ready"
+                self.optimizer.finish_step()
+            else:
+                self.optimizer.step()
         return loss.detach()
 
 
