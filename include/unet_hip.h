@@ -235,6 +235,46 @@ int uh_nchw_to_c8(int B, int Cin, int H, int W, const float* x, void* out, int o
 int uh_adam_step(long long n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2,
                  float eps, float weight_decay, int step, uh_stream s);
 
+/* ---- self-regularisation loss (models/losses.py:6-217; trainer/training_utils.py:100-101,142-143) ------------
+ * loss = 0.4*CE + 0.6*Dice + 0.015*(LSRC + LIFD) (losses.py:72).  For one-channel logits the CE term and its
+ * gradient are identically zero; LSRC and LIFD enter as constants (losses.py:63-69).
+ *
+ * Constants, from padded-linear bf16 feature maps (C a multiple of 8, at most 1024):
+ *   uh_selfreg_pool2        2x2 mean of a map (bf16 window, or fp32 rows of C floats when in_f32) -> fp32 rows of
+ *                           C floats, padded-linear for (B, Ho, Wo), pad rows zero: the levels of
+ *                           adaptive_avg_pool2d(last feature, size of feature i) (losses.py:117)
+ *   uh_selfreg_plane_stats  partial[b][part][2][C]: sum and sum of squares per image and channel (losses.py:185-189)
+ *   uh_selfreg_rank         order[C]: channels by descending mean of f / (||f||_2 + 1e-8) (losses.py:185-192),
+ *                           ties towards the lower index; uses up `partial` (its contents are overwritten)
+ *   uh_selfreg_pair_sums    partial[part][2] = ( sum (f[sel_f[j]] - pooled[sel_p[j]])^2 over rows and j < nsel
+ *                           (losses.py:128-147; pooled: a window of p_channels channels, bf16 or fp32; NULL: 0),  sum (f[order[j]] - f[order[j + C/2]])^2 over rows
+ *                           and j < C/2 (losses.py:195-206) )
+ *   uh_selfreg_accumulate   aux[0] += scale_lsrc * sum partial[.][0]; aux[1] += scale_pair * sum partial[.][1]
+ *                           (init != 0: start from zero); the scales carry 1/elements and 1/(features - 1)
+ *                           (losses.py:147,155,206,217)
+ * Differentiable part, fp32 logits and targets [B][n]:
+ *   uh_selfreg_loss_fwd     loss[0] = w_dice * (1 - mean_b (2 sum(p t) + 1e-6) / (sum(p^2) + sum(t^2) + 1e-6)),
+ *                           p = sigmoid(logits) (losses.py:18-41), + w_aux * (aux[0] + aux[1]) when aux != NULL;
+ *                           coef[B][2] is kept for the backward pass
+ *   uh_selfreg_loss_bwd     dlogits = gout[0] * d loss / d logits */
+int uh_selfreg_pool2(int B, int Ho, int Wo, int C, const void* in, int in_f32, int cstride, int coff, float* out,
+                     uh_stream s);
+int uh_selfreg_stat_parts(int B, int H, int W, int C);
+int uh_selfreg_plane_stats(int B, int H, int W, int C, const void* f, int cstride, int coff, float* partial,
+                           uh_stream s);
+int uh_selfreg_rank(int B, int H, int W, int C, float* partial, int* order, uh_stream s);
+int uh_selfreg_pair_parts(int B, int H, int W, int C);
+int uh_selfreg_pair_sums(int B, int H, int W, int C, const void* f, int cstride, int coff, const int* order,
+                         const void* pooled, int pooled_f32, int p_channels, int p_cstride, int p_coff, int nsel,
+                         const int* sel_f, const int* sel_p, float* partial, uh_stream s);
+int uh_selfreg_accumulate(const float* partial, int parts, double scale_lsrc, double scale_pair, int init, float* aux,
+                          uh_stream s);
+size_t uh_selfreg_loss_workspace(int B, long long n);
+int uh_selfreg_loss_fwd(int B, long long n, const float* logits, const float* targets, const float* aux, float w_dice,
+                        float w_aux, float* loss, float* coef, void* workspace, size_t workspace_bytes, uh_stream s);
+int uh_selfreg_loss_bwd(int B, long long n, const float* logits, const float* targets, const float* coef,
+                        const float* gout, float w_dice, float* dlogits, uh_stream s);
+
 /* ---- evaluation: binarised predictions and confusion counts, fp32 logits and masks [planes][n] ---------
  * pred = sigmoid(logit) > 0.5 evaluated in fp32 (trainer/k_fold.py:289-290; test_helper/utils.py:130-131), so
  * logit 0 and NaN are background; counted against mask == 1 / mask == 0 exactly (k_fold.py:371-380: other

@@ -186,8 +186,8 @@ def test_train_model_lunext_cldice_runs_and_early_stops(tmp_path):
     assert 1 <= len(val) <= 4 and all(np.isfinite(val)) and all(0 <= v <= 1 for v in val)
     ref = ref_cpu.RefLUNeXt(3, 1)
     ref.load_state_dict(torch.load(str(ckpt), map_location="cpu", weights_only=True))
-    with pytest.raises(NotImplementedError):
-        trainer.train_model(tr, va, custom_loss="self_reg", device=DEV)
+    with pytest.raises(ValueError):                     # the reference's LUNeXt keeps no intermediate_features either
+        trainer.train_model(tr, va, model_type="LUNeXt", custom_loss="self_reg", device=DEV)
 
 
 def test_train_kfold_single_process(tmp_path):

@@ -165,3 +165,31 @@ def test_metrics_oracle_matches_reference(golden_dir):
         for j in range(len(logits)):
             sm = om.sample_metrics(pred[j], mask[j])
             np.testing.assert_array_equal([sm[k] for k in sample_keys], fx[c + ".sample"][j], err_msg=f"{c}[{j}]")
+
+
+def selfreg_case(fx, name):
+    """(features, logits, targets, seeds, [lsrc, lifd, dice, ce, loss], dlogits) of one stored case."""
+    n = int(fx[f"{name}.n"])
+    feats = [torch.from_numpy(fx[f"{name}.f{i}"].astype(np.float32)) for i in range(n)]
+    return (feats, torch.from_numpy(fx[f"{name}.logits"]), torch.from_numpy(fx[f"{name}.targets"]),
+            [int(s) for s in fx[f"{name}.seeds"]], fx[f"{name}.scalars"], fx[f"{name}.dlogits"])
+
+
+def test_self_reg_oracle_matches_reference(golden_dir):
+    """oracle/self_reg.py against the reference's SelfRegLoss outputs (selfreg_cases.npz), the seeds of the
+    channel subsets taken from the fixture."""
+    from oracle import self_reg as osr
+    fx = _load(golden_dir, "selfreg_cases.npz")
+    names = list(fx["names"])
+    assert names == ["unet_like", "dead_channels", "final_wider", "single_feature", "two_channels"]
+    for name in names:
+        feats, logits, targets, seeds, want, dwant = selfreg_case(fx, name)
+        logits = logits.clone().requires_grad_(True)
+        np.testing.assert_allclose(float(osr.lsrc(feats, seeds)), want[0], rtol=1e-6, atol=1e-9, err_msg=name)
+        np.testing.assert_allclose(float(osr.lifd(feats)), want[1], rtol=1e-6, atol=1e-9, err_msg=name)
+        np.testing.assert_allclose(float(osr.dice_loss(logits.detach(), targets)), want[2], rtol=1e-6, err_msg=name)
+        assert float(osr.cross_entropy(logits.detach(), targets)) == 0.0 == want[3]    # one class: identically zero
+        loss = osr.self_reg_loss(logits, targets, feats, seeds)
+        np.testing.assert_allclose(float(loss), want[4], rtol=1e-6, err_msg=name)
+        loss.backward()
+        np.testing.assert_allclose(logits.grad.numpy(), dwant, rtol=1e-5, atol=1e-9, err_msg=name)

@@ -14,6 +14,7 @@ from .unet import UNet                                   # noqa: F401
 from .lunext import LUNeXt                               # noqa: F401
 from .model_utils import create_unet, create_lunext, save_model   # noqa: F401
 from .cl_dice import soft_dice_cldice, soft_cldice, soft_dice, SoftSkeletonize   # noqa: F401
+from .self_reg import SelfRegLoss                         # noqa: F401
 from .trainer import train_model, evaluate_model, calculate_metrics, save_results   # noqa: F401
 
 __all__ = ["train_model", "evaluate_model", "calculate_metrics", "save_results", "UNet", "LUNeXt", "soft_dice_cldice", "soft_cldice", "soft_dice", "SoftSkeletonize", "create_unet", "create_lunext", "save_model", "lib", "LIB_PATH", "HipKernelError"]

@@ -19,6 +19,7 @@ I = ctypes.c_int
 L = ctypes.c_longlong
 F = ctypes.c_float
 Z = ctypes.c_size_t
+D = ctypes.c_double
 
 # name -> (restype, argtypes); mirrors include/unet_hip.h one to one
 SIGNATURES = {
@@ -74,6 +75,16 @@ SIGNATURES = {
     "uh_nchw_to_c8": (I, [I, I, I, I, P, P, I, I, P]),
     "uh_adam_step": (I, [L, P, P, P, P, F, F, F, F, F, I, P]),
     "uh_confusion_counts": (I, [I, L, P, P, P, P]),
+    "uh_selfreg_pool2": (I, [I, I, I, I, P, I, I, I, P, P]),
+    "uh_selfreg_stat_parts": (I, [I, I, I, I]),
+    "uh_selfreg_plane_stats": (I, [I, I, I, I, P, I, I, P, P]),
+    "uh_selfreg_rank": (I, [I, I, I, I, P, P, P]),
+    "uh_selfreg_pair_parts": (I, [I, I, I, I]),
+    "uh_selfreg_pair_sums": (I, [I, I, I, I, P, I, I, P, P, I, I, I, I, I, P, P, P, P]),
+    "uh_selfreg_accumulate": (I, [P, I, D, D, I, P, P]),
+    "uh_selfreg_loss_workspace": (Z, [I, L]),
+    "uh_selfreg_loss_fwd": (I, [I, L, P, P, P, F, F, P, P, P, Z, P]),
+    "uh_selfreg_loss_bwd": (I, [I, L, P, P, P, P, F, P, P]),
     "uh_soft_erode": (I, [I, I, I, P, P, I, P]),
     "uh_soft_dilate": (I, [I, I, I, P, P, P]),
     "uh_soft_skel_workspace": (Z, [I, I, I]),

@@ -22,6 +22,7 @@ import torch.nn as nn
 
 from . import _lib
 from .engine import UNetRun
+from .unet import _Features, FEATURE_LAYERS
 
 
 class KernelTimer:
@@ -235,6 +236,8 @@ class DataParallelTrainer:
         run.zero_grads_kept = self._zeroed          # bucket memory: zero since the first step, summed with zeros since
         self._zeroed = True
         logits = run.forward().requires_grad_(True)
+        # what model(images) would leave behind (a criterion may read it: models/losses.py via training_utils.py:143)
+        model.intermediate_features = _Features([run.acts[n] for n in FEATURE_LAYERS], run.lease.pool)
         loss = self.criterion(logits, masks)
         # d(mean over ranks of loss)/dlogits: fold the 1/world of gradient averaging into the seed
         (dlogits,) = torch.autograd.grad(loss / self.world, logits)

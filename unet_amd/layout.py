@@ -74,6 +74,7 @@ class BufferPool:
         self.device = device
         self.free = {}          # key -> list of tensors
         self.rowmasks = {}      # (B,H,W) -> uint8 tensor
+        self.handed = {}        # id(tensor) -> times handed out (tells a reader that its buffer went to someone else)
         self.bytes_allocated = 0
 
     def rowmask(self, B, H, W):
@@ -91,6 +92,7 @@ class BufferPool:
     def clear(self):
         self.free.clear()
         self.rowmasks.clear()
+        self.handed.clear()
         self.bytes_allocated = 0
 
 
@@ -103,6 +105,7 @@ class Lease:
         lst = self.pool.free.get(key)
         t = lst.pop() if lst else make()
         self.held.append((key, t))
+        self.pool.handed[id(t)] = self.pool.handed.get(id(t), 0) + 1
         return t
 
     def act(self, B, H, W, C, cstride=None, tag=None):

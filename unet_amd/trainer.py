@@ -163,10 +163,17 @@ def confusion_counts(logits, masks, counts, per_sample=False):
     return counts
 
 
-def _make_loss(custom_loss):
+def _make_loss(custom_loss, model=None):
     """training_utils.py:100-105 and the glue in front of the loss (:142-150): a function (logits, masks) -> loss."""
     if custom_loss == "self_reg":
-        raise NotImplementedError("custom_loss='self_reg' (models/losses.py) is not part of the HIP path")
+        if model is None or not hasattr(model, "intermediate_features"):
+            raise ValueError("custom_loss='self_reg' needs a model with intermediate_features (the U-Net)")
+        from .self_reg import SelfRegLoss
+        reg = SelfRegLoss()
+
+        def self_reg_loss(logits, masks):
+            return reg(logits, masks, model.intermediate_features)      # the list the last forward pass left
+        return self_reg_loss
     if custom_loss == "cl_dice":
         crit = soft_dice_cldice()
 
@@ -198,7 +205,7 @@ def train_model(train_data, validation_data, model_type="UNet", epochs=50, batch
         model = create_lunext(in_channels=in_channels, out_channels=1)
         save_path = model_save_path or "best_lunext_model.pth"
     model = model.to(dev)
-    loss_fn = _make_loss(custom_loss)
+    loss_fn = _make_loss(custom_loss, model)
 
     if model_type == "UNet":
         stepper = DataParallelTrainer(model, lr=learning_rate, criterion=loss_fn, standalone=not data_parallel)

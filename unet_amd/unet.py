@@ -19,15 +19,31 @@ FEATURE_LAYERS = tuple(
 
 
 class _Features(list):
-    """`intermediate_features`: materialised (NCHW fp32) on first access, from the bf16 NHWC buffers."""
+    """`intermediate_features`: materialised (NCHW fp32) on first access, from the bf16 NHWC buffers.
 
-    def __init__(self, acts=None):
+    The buffers belong to the forward pass that made the list and go back to the pool when it ends (after backward,
+    or at once without gradients); they keep their contents until a later pass takes them again.  Reading the list
+    after that raises instead of returning another pass's activations."""
+
+    def __init__(self, acts=None, pool=None):
         super().__init__()
-        self._acts = acts
+        self._acts, self._pool = acts, pool
+        self._stamp = [pool.handed.get(id(a.buf), 0) for a in acts] if (pool is not None and acts) else None
+
+    def acts(self):
+        """The padded-linear bf16 views themselves, for kernels that read them in place; None once the list has
+        been materialised."""
+        if self._acts is not None and self._stamp is not None:
+            now = [self._pool.handed.get(id(a.buf), 0) for a in self._acts]
+            if now != self._stamp:
+                raise RuntimeError("intermediate_features of an earlier forward pass: its activation buffers have "
+                                   "been reused since (read them before the next forward/backward)")
+        return self._acts
 
     def _fill(self):
-        if self._acts is not None:
-            acts, self._acts = self._acts, None
+        acts = self.acts()
+        if acts is not None:
+            self._acts = None
             super().extend(a.to_nchw() for a in acts)
 
     def __len__(self):
@@ -128,7 +144,7 @@ class UNet(nn.Module):
                 xf = x.detach().float().contiguous()
                 run = UNetRun(self, xf, training=self.training)
                 logits = run.forward()
-        self.intermediate_features = _Features([run.acts[n] for n in FEATURE_LAYERS])
+        self.intermediate_features = _Features([run.acts[n] for n in FEATURE_LAYERS], run.lease.pool)
         if not need_grad:
             run.release()
         self._last_run = None
