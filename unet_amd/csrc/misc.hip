@@ -129,31 +129,39 @@ extern "C" int uh_pack_weights_multi(const uh_pack_desc* descs_device, int count
 template <bool TO_DEPTH>
 __global__ void s2d_kernel(int B, int H, int W, int C, const char* __restrict__ in, int i_cstride, int i_coff,
                            char* __restrict__ out, int o_cstride, int o_coff) {
-  const int Wp = W + 1, Hp = H + 1, oWp = 2 * W + 1, oHp = 2 * H + 1;
-  const int cpr = C / 8;
-  const long long total = (long long)B * Hp * Wp * 4 * cpr;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int cc = (int)(i % cpr);
-    long long r = i / cpr;
-    const int t = (int)(r & 3);
-    r >>= 2;
-    const int x = (int)(r % Wp);
-    r /= Wp;
-    const int y = (int)(r % Hp);
-    const long long b = r / Hp;
-    const long long ms = (b * Hp + y) * Wp + x;
-    const int Y = 2 * y + (t >> 1), X = 2 * x + (t & 1);
-    const bool big_ok = (Y < oHp && X < oWp);
-    const long long mb = (b * oHp + Y) * oWp + X;
-    const bool interior = (y < H && x < W);
-    U4 v = {0u, 0u, 0u, 0u};
+  const unsigned Wp = W + 1, Hp = H + 1, oWp = 2 * W + 1, oHp = 2 * H + 1;
+  const unsigned cpr = C / 8;
+  const unsigned total = (unsigned)B * Hp * Wp * cpr;                    // the host checks that this fits
+  // one thread moves the four taps of a (row, 8-channel chunk): one decode, four loads in flight
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const unsigned cc = i % cpr, ms = i / cpr;
+    const unsigned x = ms % Wp, r = ms / Wp, y = r % Hp, b = r / Hp;
+    const bool interior = (y < (unsigned)H && x < (unsigned)W);
+    U4 v[4];
+    long long mb[4];
+    bool big_ok[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const unsigned Y = 2 * y + (t >> 1), X = 2 * x + (t & 1);
+      big_ok[t] = (Y < oHp && X < oWp);
+      mb[t] = ((long long)b * oHp + Y) * oWp + X;
+      v[t] = U4{0u, 0u, 0u, 0u};
+    }
     if (TO_DEPTH) {
-      if (interior && big_ok) v = *(const U4*)(in + (mb * i_cstride + i_coff + cc * 8) * 2);
-      *(U4*)(out + (ms * o_cstride + o_coff + t * C + cc * 8) * 2) = v;
+      if (interior) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = *(const U4*)(in + (mb[t] * i_cstride + i_coff + cc * 8) * 2);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) *(U4*)(out + ((long long)ms * o_cstride + o_coff + t * C + cc * 8) * 2) = v[t];
     } else {
-      if (!big_ok) continue;
-      if (interior) v = *(const U4*)(in + (ms * i_cstride + i_coff + t * C + cc * 8) * 2);
-      *(U4*)(out + (mb * o_cstride + o_coff + cc * 8) * 2) = v;
+      if (interior) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = *(const U4*)(in + ((long long)ms * i_cstride + i_coff + t * C + cc * 8) * 2);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (big_ok[t]) *(U4*)(out + (mb[t] * o_cstride + o_coff + cc * 8) * 2) = v[t];
     }
   }
 }
@@ -162,7 +170,8 @@ static int s2d_launch(bool to_depth, int B, int H, int W, int C, const void* in,
                       int o_cstride, int o_coff, uh_stream s) {
   UH_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && in && out, "space/depth: bad arguments");
   UH_REQUIRE(i_cstride % 8 == 0 && i_coff % 8 == 0 && o_cstride % 8 == 0 && o_coff % 8 == 0, "space/depth: bad views");
-  const long long total = uh_mp(B, H, W) * 4 * (C / 8);
+  const long long total = uh_mp(B, H, W) * (C / 8);
+  UH_REQUIRE(total < (1ll << 31), "space/depth: %lld items", total);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 16384) blocks = 16384;
   if (to_depth)
