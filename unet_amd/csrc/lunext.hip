@@ -211,10 +211,13 @@ __global__ __launch_bounds__(256) void bn_res_relu_apply_kernel(long long Mp, in
   }
   for (long long m = (long long)blockIdx.x * rpi + rr; m < Mp; m += (long long)gridDim.x * rpi) {
     U4 o = {0u, 0u, 0u, 0u};
+    // loads issued before the mask is known (pad rows are readable): one memory latency per row, not two
+    const U4 yr = *(const U4*)(y + (m * y_cs + y_co + cc * 8) * 2);
+    const U4 xr = *(const U4*)(x + (m * x_cs + x_co + cc * 8) * 2);
     if (rowmask[m]) {
       float f[8], r[8];
-      unpack8h(*(const U4*)(y + (m * y_cs + y_co + cc * 8) * 2), f);
-      unpack8(*(const U4*)(x + (m * x_cs + x_co + cc * 8) * 2), r);
+      unpack8h(yr, f);
+      unpack8(xr, r);
 #pragma unroll
       for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j] * sc[j] + sh[j] + r[j], 0.f);
       o = pack8(f);
@@ -307,11 +310,14 @@ __global__ __launch_bounds__(256) void bn_res_relu_bwd_apply_kernel(
   }
   for (long long m = (long long)blockIdx.x * rpi + rr; m < Mp; m += (long long)gridDim.x * rpi) {
     U4 o = {0u, 0u, 0u, 0u}, o2 = {0u, 0u, 0u, 0u};
+    const U4 gr = *(const U4*)(da + (m * da_cs + da_co + cc * 8) * 2);      // before the mask is known, as above
+    const U4 yr = *(const U4*)(y + (m * y_cs + y_co + cc * 8) * 2);
+    const U4 xr = *(const U4*)(x + (m * x_cs + x_co + cc * 8) * 2);
     if (rowmask[m]) {
       float g[8], v[8], r[8];
-      unpack8(*(const U4*)(da + (m * da_cs + da_co + cc * 8) * 2), g);
-      unpack8h(*(const U4*)(y + (m * y_cs + y_co + cc * 8) * 2), v);
-      unpack8(*(const U4*)(x + (m * x_cs + x_co + cc * 8) * 2), r);
+      unpack8(gr, g);
+      unpack8h(yr, v);
+      unpack8(xr, r);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float d = (v[j] * sc[j] + sh[j] + r[j] > 0.f) ? g[j] : 0.f;
