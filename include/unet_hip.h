@@ -117,8 +117,10 @@ int uh_conv_first_wgrad_parts(int B, int H, int W);
 
 /* ---- BatchNorm2d (train) + ReLU (unet.py:99-169, defaults eps 1e-5 momentum 0.1) --------- */
 /* stats: partial[P][2][C] -> mean, invstd, scale = gamma*invstd, shift = beta - mean*scale;
- * running_mean/var (unbiased var) and num_batches_tracked updated in place when non-null. */
-int uh_bn_finalize(const float* partial, int P, int C, long long count,
+ * running_mean/var (unbiased var) and num_batches_tracked updated in place when non-null.
+ * c_real <= C: gamma, beta and the running statistics hold c_real entries; channels from c_real on are layout
+ * padding (scale = shift = 0). */
+int uh_bn_finalize(const float* partial, int P, int C, int c_real, long long count,
                    const float* gamma, const float* beta, float eps, float momentum,
                    float* mean, float* invstd, float* scale, float* shift,
                    float* running_mean, float* running_var, long long* num_batches_tracked, uh_stream s);
@@ -135,8 +137,9 @@ int uh_bn_relu_bwd_reduce(long long Mp, int C, const void* da, int da_cstride, i
                           const void* y, int y_cstride, int y_coff,
                           const float* mean, const float* invstd, const float* scale, const float* shift,
                           float* partial, uh_stream s);
-/* dgamma = sum dyh*xhat, dbeta = sum dyh, coef[0][c] = dbeta/count, coef[1][c] = dgamma/count */
-int uh_bn_bwd_finalize(const float* partial, int P, int C, long long count,
+/* dgamma = sum dyh*xhat, dbeta = sum dyh (c_real entries each), coef[0][c] = dbeta/count, coef[1][c] = dgamma/count
+ * (C entries each) */
+int uh_bn_bwd_finalize(const float* partial, int P, int C, int c_real, long long count,
                        float* dgamma, float* dbeta, float* coef, int accumulate, uh_stream s);
 /* dy = scale * (dyh - coef0 - xhat*coef1) on interior rows, 0 on pads */
 int uh_bn_relu_bwd_apply(long long Mp, int C, const void* da, int da_cstride, int da_coff,
@@ -216,6 +219,9 @@ int uh_gate_bwd(long long Mp, int C, const void* dout, int d_cstride, int d_coff
 /* out = a + b (+ c when c != null) */
 int uh_add(long long Mp, int C, const void* a, int a_cstride, int a_coff, const void* b, int b_cstride, int b_coff,
            const void* c, int c_cstride, int c_coff, void* out, int o_cstride, int o_coff, uh_stream s);
+/* weight gradient of the depthwise convolution: the partial[parts][9][C] rows of uh_dwconv3x3_wgrad summed into the
+ * module's own layout out[c_real][1][3][3] (lunext.py:14), padding channels dropped */
+int uh_dw_wgrad_finalize(const float* partial, int parts, int C, int c_real, float* out, uh_stream s);
 /* fully fused gate for the 8-channel top level; wts = W1[8][8]|W2[8][8]|W3[8][8]|b1[8]|b2[8]|b3[8] fp32
  * ([co][ci], zero beyond the c_real real channels; only those are computed),
  * partial[blk][216] (blk < uh_gate8_parts) holds the weight gradients in the same layout */

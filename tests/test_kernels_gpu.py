@@ -340,7 +340,7 @@ def test_batchnorm_relu_forward_backward(B, H, W, C):
     gd, bd, rm, rv = gamma.to(DEV), beta.to(DEV), rm0.to(DEV), rv0.to(DEV)
     nbt = torch.tensor(5, dtype=torch.int64, device=DEV)
     st = torch.empty(4, C, device=DEV)
-    call("uh_bn_finalize", pd.data_ptr(), 2, C, B * H * W, gd.data_ptr(), bd.data_ptr(), 1e-5, 0.1, st[0].data_ptr(),
+    call("uh_bn_finalize", pd.data_ptr(), 2, C, C, B * H * W, gd.data_ptr(), bd.data_ptr(), 1e-5, 0.1, st[0].data_ptr(),
          st[1].data_ptr(), st[2].data_ptr(), st[3].data_ptr(), rm.data_ptr(), rv.data_ptr(), nbt.data_ptr(), S())
     ya = act_from(y, half=True)
     a = new_act(B, H, W, C, DEV)
@@ -368,7 +368,7 @@ def test_batchnorm_relu_forward_backward(B, H, W, C):
     call("uh_bn_relu_bwd_reduce", ya.Mp, C, dact.ptr, dact.cstride, dact.coff, ya.ptr, ya.cstride, ya.coff,
          st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(), st[3].data_ptr(), bp.data_ptr(), S())
     dg, db, coef = torch.empty(C, device=DEV), torch.empty(C, device=DEV), torch.empty(2, C, device=DEV)
-    call("uh_bn_bwd_finalize", bp.data_ptr(), parts, C, B * H * W, dg.data_ptr(), db.data_ptr(), coef.data_ptr(), 0, S())
+    call("uh_bn_bwd_finalize", bp.data_ptr(), parts, C, C, B * H * W, dg.data_ptr(), db.data_ptr(), coef.data_ptr(), 0, S())
     dy = new_act(B, H, W, C, DEV)
     call("uh_bn_relu_bwd_apply", ya.Mp, C, dact.ptr, dact.cstride, dact.coff, ya.ptr, ya.cstride, ya.coff,
          st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(), st[3].data_ptr(), coef.data_ptr(), mask.data_ptr(),

@@ -42,12 +42,12 @@ SIGNATURES = {
     "uh_conv_first_parts": (I, [I, I, I]),
     "uh_conv_first_wgrad": (I, [I, I, I, I, I, P, P, I, I, P, P]),
     "uh_conv_first_wgrad_parts": (I, [I, I, I]),
-    "uh_bn_finalize": (I, [P, I, I, L, P, P, F, F, P, P, P, P, P, P, P, P]),
+    "uh_bn_finalize": (I, [P, I, I, I, L, P, P, F, F, P, P, P, P, P, P, P, P]),
     "uh_bn_fold_eval": (I, [I, P, P, P, P, P, F, P, P, P]),
     "uh_bn_relu_apply": (I, [L, I, P, I, I, P, P, P, P, I, I, P]),
     "uh_bn_bwd_parts": (I, [L, I]),
     "uh_bn_relu_bwd_reduce": (I, [L, I, P, I, I, P, I, I, P, P, P, P, P, P]),
-    "uh_bn_bwd_finalize": (I, [P, I, I, L, P, P, P, I, P]),
+    "uh_bn_bwd_finalize": (I, [P, I, I, I, L, P, P, P, I, P]),
     "uh_bn_relu_bwd_apply": (I, [L, I, P, I, I, P, I, I, P, P, P, P, P, P, P, I, I, P]),
     "uh_maxpool2_fwd": (I, [I, I, I, I, P, I, I, P, I, I, P]),
     "uh_maxpool2_bwd": (I, [I, I, I, I, P, I, I, P, I, I, P, I, I, P, I, I, P]),
@@ -66,6 +66,7 @@ SIGNATURES = {
     "uh_bn_res_relu_bwd_apply": (I, [L, I, P, I, I, P, I, I, P, I, I, P, P, P, P, P, P, P, I, I, P, I, I, P]),
     "uh_dwconv3x3_dgrad": (I, [I, I, I, I, P, I, I, P, I, P, I, I, P, P, I, I, P]),
     "uh_dwconv3x3_wgrad": (I, [I, I, I, I, P, I, I, P, I, I, P, P]),
+    "uh_dw_wgrad_finalize": (I, [P, I, I, I, P, P]),
     "uh_gate_fwd": (I, [L, I, P, I, I, P, I, I, P, I, I, P]),
     "uh_gate_bwd": (I, [L, I, P, I, I, P, I, I, P, I, I, P, P, I, I, P, I, I, P]),
     "uh_add": (I, [L, I, P, I, I, P, I, I, P, I, I, P, I, I, P]),

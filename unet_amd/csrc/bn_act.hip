@@ -6,7 +6,7 @@
 // combined through LDS once per workgroup and written as one partial row per workgroup.
 #include "ew.h"
 
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ partial, int P, int C,
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ partial, int P, int C, int c_real,
                                                            double count, const float* gamma, const float* beta,
                                                            float eps, float momentum, float* mean_o, float* invstd_o,
                                                            float* scale_o, float* shift_o, float* rm, float* rv,
@@ -22,12 +22,13 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
     double var = s[1] / count - mean * mean;
     if (var < 0.0) var = 0.0;
     const double invstd = 1.0 / sqrt(var + (double)eps);
-    const double sc = (double)gamma[c] * invstd;
+    const bool real = c < c_real;                     // padding channels: gamma = beta = 0, no running statistics
+    const double sc = real ? (double)gamma[c] * invstd : 0.0;
     mean_o[c] = (float)mean;
     invstd_o[c] = (float)invstd;
     scale_o[c] = (float)sc;
-    shift_o[c] = (float)((double)beta[c] - mean * sc);
-    if (rm) {
+    shift_o[c] = real ? (float)((double)beta[c] - mean * sc) : 0.f;
+    if (rm && real) {
       const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
       rm[c] = (float)((1.0 - momentum) * rm[c] + momentum * mean);
       rv[c] = (float)((1.0 - momentum) * rv[c] + momentum * unbiased);
@@ -36,14 +37,15 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
   if (nbt && blockIdx.x == 0 && t == 0) *nbt += 1;
 }
 
-extern "C" int uh_bn_finalize(const float* partial, int P, int C, long long count, const float* gamma,
+extern "C" int uh_bn_finalize(const float* partial, int P, int C, int c_real, long long count, const float* gamma,
                               const float* beta, float eps, float momentum, float* mean, float* invstd, float* scale,
                               float* shift, float* running_mean, float* running_var, long long* nbt, uh_stream s) {
-  UH_REQUIRE(partial && gamma && beta && mean && invstd && scale && shift && P > 0 && C > 0 && count > 0,
+  UH_REQUIRE(partial && gamma && beta && mean && invstd && scale && shift && P > 0 && C > 0 && count > 0 &&
+                 c_real > 0 && c_real <= C,
              "bn_finalize: bad arguments");
   UH_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running stats must come in pairs");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 7) / 8), dim3(1024), 0, (hipStream_t)s, partial, P, C, (double)count,
-                     gamma, beta, eps, momentum, mean, invstd, scale, shift, running_mean, running_var, nbt);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 7) / 8), dim3(1024), 0, (hipStream_t)s, partial, P, C, c_real,
+                     (double)count, gamma, beta, eps, momentum, mean, invstd, scale, shift, running_mean, running_var, nbt);
   return uh_check_launch("bn_finalize");
 }
 
@@ -180,8 +182,8 @@ extern "C" int uh_bn_relu_bwd_reduce(long long Mp, int C, const void* da, int da
 }
 
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int P, int C,
-                                                               double count, float* dgamma, float* dbeta, float* coef,
-                                                               int accumulate) {
+                                                               int c_real, double count, float* dgamma, float* dbeta,
+                                                               float* coef, int accumulate) {
   __shared__ double lds[128 * 2 * 8];
   const int c0 = blockIdx.x * 8;
   double s[2];
@@ -189,17 +191,20 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
   const int t = threadIdx.x;
   if (t < 8 && c0 + t < C) {
     const int c = c0 + t;
-    dbeta[c] = accumulate ? dbeta[c] + (float)s[0] : (float)s[0];
-    dgamma[c] = accumulate ? dgamma[c] + (float)s[1] : (float)s[1];
+    if (c < c_real) {                                 // dgamma/dbeta hold c_real entries
+      dbeta[c] = accumulate ? dbeta[c] + (float)s[0] : (float)s[0];
+      dgamma[c] = accumulate ? dgamma[c] + (float)s[1] : (float)s[1];
+    }
     coef[c] = (float)(s[0] / count);
     coef[C + c] = (float)(s[1] / count);
   }
 }
 
-extern "C" int uh_bn_bwd_finalize(const float* partial, int P, int C, long long count, float* dgamma, float* dbeta,
-                                  float* coef, int accumulate, uh_stream s) {
-  UH_REQUIRE(partial && dgamma && dbeta && coef && P > 0 && C > 0 && count > 0, "bn_bwd_finalize: bad arguments");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 7) / 8), dim3(1024), 0, (hipStream_t)s, partial, P, C,
+extern "C" int uh_bn_bwd_finalize(const float* partial, int P, int C, int c_real, long long count, float* dgamma,
+                                  float* dbeta, float* coef, int accumulate, uh_stream s) {
+  UH_REQUIRE(partial && dgamma && dbeta && coef && P > 0 && C > 0 && count > 0 && c_real > 0 && c_real <= C,
+             "bn_bwd_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 7) / 8), dim3(1024), 0, (hipStream_t)s, partial, P, C, c_real,
                      (double)count, dgamma, dbeta, coef, accumulate);
   return uh_check_launch("bn_bwd_finalize");
 }

@@ -479,6 +479,34 @@ extern "C" int uh_dwconv3x3_wgrad(int B, int H, int W, int C, const void* dy, in
   return uh_check_launch("dwconv3x3_wgrad");
 }
 
+// partial[P][9][C] -> the module's own weight-gradient layout out[c_real][1][3][3] (padding channels dropped)
+__global__ __launch_bounds__(1024) void dw_wgrad_finalize_kernel(const float* __restrict__ partial, int P, int C,
+                                                                 int c_real, float* __restrict__ out) {
+  __shared__ double lds[128 * 8];
+  const int ncol = 9 * C, c0 = blockIdx.x * 8;
+  const int t = threadIdx.x, c8 = t & 7, slot = t >> 3;
+  double s = 0.0;
+  if (c0 + c8 < ncol)
+    for (int p = slot; p < P; p += 128) s += (double)partial[(long long)p * ncol + c0 + c8];
+  lds[slot * 8 + c8] = s;
+  __syncthreads();
+  for (int stride = 64; stride > 0; stride >>= 1) {
+    if (slot < stride) lds[slot * 8 + c8] += lds[(slot + stride) * 8 + c8];
+    __syncthreads();
+  }
+  if (t < 8 && c0 + t < ncol) {
+    const int tap = (c0 + t) / C, c = (c0 + t) % C;
+    if (c < c_real) out[c * 9 + tap] = (float)lds[t];
+  }
+}
+
+extern "C" int uh_dw_wgrad_finalize(const float* partial, int P, int C, int c_real, float* out, uh_stream s) {
+  UH_REQUIRE(partial && out && P > 0 && C > 0 && c_real > 0 && c_real <= C, "dw_wgrad_finalize: bad arguments");
+  hipLaunchKernelGGL(dw_wgrad_finalize_kernel, dim3((9 * C + 7) / 8), dim3(1024), 0, (hipStream_t)s, partial, P, C,
+                     c_real, out);
+  return uh_check_launch("dw_wgrad_finalize");
+}
+
 // ---- attention gate, pointwise parts (C >= 64; z = [z1 | z2 | z3] pre-activations, 3C channels) ----------------------
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf(-v)); }
 

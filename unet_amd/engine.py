@@ -128,7 +128,7 @@ class UNetRun:
         B, H, W = self.geo[lvl]
         C = rec.cout
         rec.mean, rec.invstd, rec.scale, rec.shift = self._bn_params(C)
-        call("uh_bn_finalize", stat.data_ptr(), parts, C, B * H * W, bn.weight.data_ptr(), bn.bias.data_ptr(),
+        call("uh_bn_finalize", stat.data_ptr(), parts, C, C, B * H * W, bn.weight.data_ptr(), bn.bias.data_ptr(),
              BN_EPS, BN_MOMENTUM, rec.mean.data_ptr(), rec.invstd.data_ptr(), rec.scale.data_ptr(),
              rec.shift.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
              bn.num_batches_tracked.data_ptr(), _stream())
@@ -268,7 +268,7 @@ class UNetRun:
         dgamma = self._galloc(bnname + ".weight", (C,))
         dbeta = self._galloc(bnname + ".bias", (C,))
         coef = L.f32(2 * C)
-        call("uh_bn_bwd_finalize", partial.data_ptr(), parts, C, B * H * W, dgamma.data_ptr(), dbeta.data_ptr(),
+        call("uh_bn_bwd_finalize", partial.data_ptr(), parts, C, C, B * H * W, dgamma.data_ptr(), dbeta.data_ptr(),
              coef.data_ptr(), 0, s)
         grads[bnname + ".weight"], grads[bnname + ".bias"] = dgamma, dbeta
         dy = L.act(B, H, W, C)

@@ -20,6 +20,7 @@ from . import _lib
 from ._lib import call, EPI_RAW_STATS, EPI_AFFINE_RELU, EPI_MASKED, EPI_CONVT
 from .engine import BN_EPS, BN_MOMENTUM, _stream, _SIDE_STREAMS
 from .layout import pool_for
+from .packing import lunext_packer_for
 
 L = _lib.lib
 
@@ -59,8 +60,9 @@ class LUNeXtRun:
         self.cp = [_padc(c) for c in self.chans]
         self.recs = {}
         self.saved = {}
-        self._deferred = []                      # (gradient name, closure) to run once the second stream is joined
         self._side_used = None
+        self.packer = lunext_packer_for(module, x.device)       # bf16 GEMM operands, one repack launch per direction
+        self.wf = None
 
     # ------------------------------------------------------------------ depthwise block
     def _dw(self, name, x, lvl):
@@ -71,10 +73,10 @@ class LUNeXtRun:
         wt, bias = blk.depthwise.weight.detach(), blk.depthwise.bias.detach()      # read in place by the kernels
         if wt.data_ptr() % 16 or not wt.is_contiguous():
             wt = wt.clone(memory_format=torch.contiguous_format)
-        gamma, beta = _padv(blk.bn.weight, Cp), _padv(blk.bn.bias, Cp)
         mask = self.masks[lvl]
         a = Ls.act(B, H, W, Cp)
         if not self.training:
+            gamma, beta = _padv(blk.bn.weight, Cp), _padv(blk.bn.bias, Cp)
             rm, rv = _padv(blk.bn.running_mean, Cp), _padv(blk.bn.running_var, Cp, 1.0)
             f = Ls.f32(2 * Cp)
             call("uh_bn_fold_eval", Cp, gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(), None, BN_EPS,
@@ -92,15 +94,11 @@ class LUNeXtRun:
              None, None, mask.data_ptr(), rec.y.ptr, rec.y.cstride, rec.y.coff, stat.data_ptr(), s)
         f = Ls.f32(4 * Cp)
         rec.mean, rec.invstd, rec.scale, rec.shift = f[:Cp], f[Cp:2 * Cp], f[2 * Cp:3 * Cp], f[3 * Cp:]
-        padded = Cp != C
-        rm = _padv(blk.bn.running_mean, Cp) if padded else blk.bn.running_mean
-        rv = _padv(blk.bn.running_var, Cp, 1.0) if padded else blk.bn.running_var
-        call("uh_bn_finalize", stat.data_ptr(), parts, Cp, B * H * W, gamma.data_ptr(), beta.data_ptr(), BN_EPS,
-             BN_MOMENTUM, rec.mean.data_ptr(), rec.invstd.data_ptr(), rec.scale.data_ptr(), rec.shift.data_ptr(),
-             rm.data_ptr(), rv.data_ptr(), blk.bn.num_batches_tracked.data_ptr(), s)
-        if padded:
-            blk.bn.running_mean.copy_(rm[:C])
-            blk.bn.running_var.copy_(rv[:C])
+        # the C real channels of the parameters and running statistics are read and updated where they are
+        call("uh_bn_finalize", stat.data_ptr(), parts, Cp, C, B * H * W, blk.bn.weight.data_ptr(),
+             blk.bn.bias.data_ptr(), BN_EPS, BN_MOMENTUM, rec.mean.data_ptr(), rec.invstd.data_ptr(),
+             rec.scale.data_ptr(), rec.shift.data_ptr(), blk.bn.running_mean.data_ptr(),
+             blk.bn.running_var.data_ptr(), blk.bn.num_batches_tracked.data_ptr(), s)
         call("uh_bn_res_relu_apply", x.Mp, Cp, rec.y.ptr, rec.y.cstride, rec.y.coff, x.ptr, x.cstride, x.coff,
              rec.scale.data_ptr(), rec.shift.data_ptr(), mask.data_ptr(), a.ptr, a.cstride, a.coff, s)
         self.recs[name] = rec
@@ -118,29 +116,21 @@ class LUNeXtRun:
         call("uh_bn_res_relu_bwd_reduce", x.Mp, Cp, da.ptr, da.cstride, da.coff, y.ptr, y.cstride, y.coff, x.ptr,
              x.cstride, x.coff, *st, partial.data_ptr(), s)
         coef = Ls.f32(2 * Cp)
-        if Cp == C:                                  # no channel padding: the kernel writes the gradient tensors themselves
-            dg = torch.empty(C, dtype=torch.float32, device=self.device)
-            db = torch.empty(C, dtype=torch.float32, device=self.device)
-        else:
-            dg, db = Ls.f32(Cp), Ls.f32(Cp)
-        call("uh_bn_bwd_finalize", partial.data_ptr(), parts, Cp, B * H * W, dg.data_ptr(), db.data_ptr(),
+        dgb = torch.empty(2, C, dtype=torch.float32, device=self.device)     # the kernel writes the gradient tensors
+        call("uh_bn_bwd_finalize", partial.data_ptr(), parts, Cp, C, B * H * W, dgb[0].data_ptr(), dgb[1].data_ptr(),
              coef.data_ptr(), 0, s)
-        if Cp == C:
-            grads[name + ".bn.weight"], grads[name + ".bn.bias"] = dg, db
-        else:
-            grads[name + ".bn.weight"], grads[name + ".bn.bias"] = dg[:C].clone(), db[:C].clone()
+        grads[name + ".bn.weight"], grads[name + ".bn.bias"] = dgb[0], dgb[1]
         dy, dr = Ls.act(B, H, W, Cp), Ls.act(B, H, W, Cp)
         call("uh_bn_res_relu_bwd_apply", x.Mp, Cp, da.ptr, da.cstride, da.coff, y.ptr, y.cstride, y.coff, x.ptr,
              x.cstride, x.coff, *st, coef.data_ptr(), mask.data_ptr(), dy.ptr, dy.cstride, dy.coff, dr.ptr, dr.cstride,
              dr.coff, s)
         wparts = L.uh_dw_parts(B, H, W, Cp)
         wp = Ls.f32(wparts * 9 * Cp)
-        w9g = Ls.f32(9 * Cp)
+        dw = torch.empty(C, 1, 3, 3, dtype=torch.float32, device=self.device)
         with self._side() as s2:                     # beside the input gradient below: both only read dy and x
             call("uh_dwconv3x3_wgrad", B, H, W, Cp, dy.ptr, dy.cstride, dy.coff, x.ptr, x.cstride, x.coff, wp.data_ptr(), s2)
-            call("uh_colsum_finalize", wp.data_ptr(), wparts, 9 * Cp, 1, w9g.data_ptr(), 0, s2)
-        self._deferred.append((name + ".depthwise.weight",
-                               lambda: w9g.view(9, Cp)[:, :C].t().reshape(C, 1, 3, 3).contiguous()))
+            call("uh_dw_wgrad_finalize", wp.data_ptr(), wparts, Cp, C, dw.data_ptr(), s2)
+        grads[name + ".depthwise.weight"] = dw
         # conv bias in front of train-mode BatchNorm: exactly zero gradient
         grads[name + ".depthwise.bias"] = self._zeros(C)
         dx = Ls.act(B, H, W, Cp)
@@ -158,8 +148,7 @@ class LUNeXtRun:
         s, Ls = _stream(), self.lease
         x4 = Ls.act(Bs, Hs, Ws, K, tag=f"down{l}.x4")
         call("uh_space_to_depth2", Bs, Hs, Ws, cpi, x.ptr, x.cstride, x.coff, x4.ptr, x4.cstride, 0, s)
-        wp = Ls.bf16_flat(cout * K, tag=f"down{l}.w")
-        call("uh_pack_weights", conv.weight.data_ptr(), wp.data_ptr(), cout, 4, cin, cin * 4, 1, 4, K, cpi, 0, s)
+        wp = self.wf[f"down{l}"]
         out = Ls.act(Bs, Hs, Ws, cout)
         call("uh_conv_gemm", Bs, Hs, Ws, x4.ptr, x4.cstride, 0, K, wp.data_ptr(), cout, 1, EPI_MASKED, out.ptr,
              out.cstride, out.coff, conv.bias.data_ptr(), None, None, None, self.masks[l].data_ptr(), s)
@@ -183,8 +172,7 @@ class LUNeXtRun:
                  dw.data_ptr(), 0, s2)
         grads[f"downconv{l}.weight"] = dw
         # dx4[m][t*cpi + ci] = sum_co dy[m][co] * W[co][ci][t]
-        wd = Ls.bf16_flat(K * cout, tag=f"down{l}.wd")
-        call("uh_pack_weights", conv.weight.data_ptr(), wd.data_ptr(), cin, 4, cout, 4, 1, cin * 4, cout, cpi * cout, 0, s)
+        wd = self.wb[f"down{l}"]
         dx4 = Ls.act(Bs, Hs, Ws, K)
         call("uh_conv_gemm", Bs, Hs, Ws, dy.ptr, dy.cstride, dy.coff, cout, wd.data_ptr(), K, 1, EPI_MASKED, dx4.ptr,
              dx4.cstride, 0, None, None, None, None, self.masks[l].data_ptr(), s)
@@ -202,8 +190,7 @@ class LUNeXtRun:
         N = max(64, 4 * cpo)
         Bs, Hs, Ws = self.geo[l + 1]
         s, Ls = _stream(), self.lease
-        wp = Ls.bf16_flat(N * cin, tag=f"up{k}.w")
-        call("uh_pack_weights", up.weight.data_ptr(), wp.data_ptr(), cout, 4, cin, 4, 1, cout * 4, cin, cpo * cin, 0, s)
+        wp = self.wf[f"up{k}"]
         out = Ls.act(*self.geo[l], cpo)
         bias = _padv(up.bias, cpo)
         call("uh_conv_gemm", Bs, Hs, Ws, x.ptr, x.cstride, x.coff, cin, wp.data_ptr(), N, 1, EPI_CONVT, out.ptr,
@@ -218,7 +205,7 @@ class LUNeXtRun:
         cin, cout, cpo = self.chans[l + 1], self.chans[l], self.cp[l]
         Bs, Hs, Ws = self.geo[l + 1]
         s, Ls = _stream(), self.lease
-        grads[f"upconv{k}.bias"] = self._colsum(dup, cpo)[:cout].clone()
+        grads[f"upconv{k}.bias"] = self._colsum(dup, cpo)[:cout]           # a view of a tensor made for this gradient
         d4 = Ls.act(Bs, Hs, Ws, N, tag=f"up{k}.d4")
         call("uh_space_to_depth2", Bs, Hs, Ws, cpo, dup.ptr, dup.cstride, dup.coff, d4.ptr, d4.cstride, 0, s)
         S = L.uh_conv_wgrad_splits(Bs, Hs, Ws, N, cin, 1)
@@ -229,8 +216,7 @@ class LUNeXtRun:
             call("uh_wgrad_reduce_strided", part.data_ptr(), S, N * cin, cout, 4, cin, cin, cpo * cin, 4, 1, cout * 4,
                  dw.data_ptr(), 0, s2)
         grads[f"upconv{k}.weight"] = dw
-        wd = Ls.bf16_flat(cin * N, tag=f"up{k}.wd")
-        call("uh_pack_weights", up.weight.data_ptr(), wd.data_ptr(), cin, 4, cout, cout * 4, 1, 4, N, cpo, 0, s)
+        wd = self.wb[f"up{k}"]
         dx = Ls.act(Bs, Hs, Ws, cin)
         call("uh_conv_gemm", Bs, Hs, Ws, d4.ptr, d4.cstride, 0, N, wd.data_ptr(), cin, 1, EPI_MASKED, dx.ptr,
              dx.cstride, dx.coff, None, None, None, None, self.masks[l + 1].data_ptr(), s)
@@ -293,11 +279,7 @@ class LUNeXtRun:
         ssum = Ls.act(B, H, W, C)
         call("uh_add", g.Mp, C, g.ptr, g.cstride, g.coff, x.ptr, x.cstride, x.coff, None, 0, 0, ssum.ptr, ssum.cstride,
              ssum.coff, s)
-        w12 = Ls.bf16_flat(2 * C * C)
-        call("uh_pack_weights", att.sigmoid_conv.weight.data_ptr(), w12.data_ptr(), C, 1, C, C, 0, 1, C, 0, 0, s)
-        call("uh_pack_weights", att.tanh_conv.weight.data_ptr(), w12.data_ptr() + C * C * 2, C, 1, C, C, 0, 1, C, 0, 0, s)
-        w3 = Ls.bf16_flat(C * C)
-        call("uh_pack_weights", att.combine_conv.weight.data_ptr(), w3.data_ptr(), C, 1, C, C, 0, 1, C, 0, 0, s)
+        w12, w3 = self.wf[f"att{k}.w12"], self.wf[f"att{k}.w3"]
         b12 = torch.cat([att.sigmoid_conv.bias.detach(), att.tanh_conv.bias.detach()])
         z = Ls.act(B, H, W, 3 * C)
         mask = self.masks[l]
@@ -324,11 +306,11 @@ class LUNeXtRun:
             part = Ls.f32(parts * 216)
             call("uh_gate8_bwd", g.Mp, C, dout.ptr, dout.cstride, dout.coff, g.ptr, g.cstride, g.coff, x.ptr, x.cstride,
                  x.coff, wts.data_ptr(), dg.ptr, dg.cstride, dg.coff, dx.ptr, dx.cstride, dx.coff, part.data_ptr(), s)
-            gw = Ls.f32(216)
+            gw = torch.empty(216, dtype=torch.float32, device=self.device)   # made for these gradients: views below
             call("uh_colsum_finalize", part.data_ptr(), parts, 216, 1, gw.data_ptr(), 0, s)
             for j, nm in enumerate(("sigmoid_conv", "tanh_conv", "combine_conv")):
-                grads[pre + nm + ".weight"] = gw[64 * j:64 * j + 64].view(8, 8)[:C, :C].reshape(C, C, 1, 1).contiguous()
-                grads[pre + nm + ".bias"] = gw[192 + 8 * j:192 + 8 * j + C].clone()
+                grads[pre + nm + ".weight"] = gw[64 * j:64 * j + 64].view(8, 8)[:C, :C].reshape(C, C, 1, 1)
+                grads[pre + nm + ".bias"] = gw[192 + 8 * j:192 + 8 * j + C]
             return dg, dx
         g, x, ssum, z = self.saved[f"att{k}"]
         mask = self.masks[l]
@@ -337,7 +319,7 @@ class LUNeXtRun:
              mask.data_ptr(), dz.ptr, dz.cstride, 0, dxd.ptr, dxd.cstride, dxd.coff, s)
         db = self._colsum(dz, 3 * C)
         for j, nm in enumerate(("sigmoid_conv", "tanh_conv", "combine_conv")):
-            grads[pre + nm + ".bias"] = db[j * C:(j + 1) * C].clone()
+            grads[pre + nm + ".bias"] = db[j * C:(j + 1) * C]
         # weight gradients: [dW1; dW2] = dz[:, :2C]^T g,  dW3 = dz[:, 2C:]^T (g + x)
         S = L.uh_conv_wgrad_splits(B, H, W, 2 * C, C, 1)
         part = Ls.f32(S * 2 * C * C)
@@ -355,14 +337,11 @@ class LUNeXtRun:
         call("uh_wgrad_reduce", part3.data_ptr(), S3, C, 1, C, C, 0, C, 0, 1, dw3.data_ptr(), 0, s)
         grads[pre + "combine_conv.weight"] = dw3
         # input gradients: dg = sum_j dz_j W_j (one GEMM over K = 3C),  ds = dz_3 W_3,  dx = dout*a + ds
-        wd = Ls.bf16_flat(C * 3 * C)
-        for j, conv in enumerate((att.sigmoid_conv, att.tanh_conv, att.combine_conv)):
-            call("uh_pack_weights", conv.weight.data_ptr(), wd.data_ptr() + j * C * 2, C, 1, C, 1, 0, C, 3 * C, 0, 0, s)
+        wd = self.wb[f"att{k}.wd"]
         dg = Ls.act(B, H, W, C)
         call("uh_conv_gemm", B, H, W, dz.ptr, dz.cstride, 0, 3 * C, wd.data_ptr(), C, 1, EPI_MASKED, dg.ptr,
              dg.cstride, dg.coff, None, None, None, None, mask.data_ptr(), s)
-        wd3 = Ls.bf16_flat(C * C)
-        call("uh_pack_weights", att.combine_conv.weight.data_ptr(), wd3.data_ptr(), C, 1, C, 1, 0, C, C, 0, 0, s)
+        wd3 = self.wb[f"att{k}.wd3"]
         ds = Ls.act(B, H, W, C)
         call("uh_conv_gemm", B, H, W, dz.ptr, dz.cstride, 2 * C, C, wd3.data_ptr(), C, 1, EPI_MASKED, ds.ptr,
              ds.cstride, ds.coff, None, None, None, None, mask.data_ptr(), s)
@@ -374,6 +353,7 @@ class LUNeXtRun:
     # ------------------------------------------------------------------ whole network
     def forward(self):
         m, Ls, s = self.m, self.lease, _stream()
+        self.wf = self.packer.get("fwd", s)
         B, H, W = self.geo[0]
         cin = self.chans[0]
         cur = Ls.act(B, H, W, 8)
@@ -403,6 +383,7 @@ class LUNeXtRun:
         if not self.training:
             raise RuntimeError("backward through an eval-mode forward is not built; call model.train() first")
         m, Ls, s = self.m, self.lease, _stream()
+        self.wb = self.packer.get("bwd", s)
         grads = {}
         B, H, W = self.geo[0]
         cin, oc = self.chans[0], m.out_channels
@@ -413,11 +394,10 @@ class LUNeXtRun:
         hp = Ls.f32(parts * oc * 9)
         call("uh_head_bwd", B, H, W, 8, oc, a.ptr, a.cstride, a.coff, self.head_w.data_ptr(), dl.data_ptr(), da.ptr,
              da.cstride, da.coff, hp.data_ptr(), s)
-        hw = Ls.f32(oc * 9)
+        hw = torch.empty(oc, 9, dtype=torch.float32, device=self.device)    # made for these gradients: views below
         call("uh_colsum_finalize", hp.data_ptr(), parts, oc * 9, 1, hw.data_ptr(), 0, s)
-        hw = hw.view(oc, 9)
-        grads["final_conv.weight"] = hw[:, :cin].reshape(oc, cin, 1, 1).clone()
-        grads["final_conv.bias"] = hw[:, 8].clone()
+        grads["final_conv.weight"] = hw[:, :cin].reshape(oc, cin, 1, 1)
+        grads["final_conv.bias"] = hw[:, 8]
         skip_grads = [None] * 4
         for k in range(4, 0, -1):
             l = 4 - k
@@ -437,9 +417,6 @@ class LUNeXtRun:
             da = self._dw_backward(f"conv{l}_1", self._dw_backward(f"conv{l}_2", tot, grads), grads)
         if self._side_used is not None:
             torch.cuda.current_stream().wait_stream(self._side_used)
-        for n, make in self._deferred:
-            grads[n] = make()
-        self._deferred = []
         return grads
 
     def release(self):

@@ -75,6 +75,81 @@ class WeightPacker:
         return g["views"]
 
 
+def lunext_pack_plan(module):
+    """Buffers and entries of every packed operand of a LUNeXt (models/lunext.py:139-185): the 2x2 stride-2
+    convolutions, the transposed convolutions and the gates' 1x1 convolutions at 64 channels and more.
+
+    Returns ({direction: {key: elements}}, [(direction, key, element offset, parameter, N, T, K, sn, st, sk, on, ot)]).
+    Operands narrower than the 64 columns/rows the GEMM kernels work on are zero-padded: the buffers start as zeros
+    and the repack writes the real entries only."""
+    chans = [module.in_channels, 64, 128, 256, 512]
+    cp = [max(8, (c + 7) // 8 * 8) for c in chans]
+    sizes = {"fwd": {}, "bwd": {}}
+    entries = []
+    for l in range(1, 5):
+        w = getattr(module, f"downconv{l}").weight                   # [cout][cin][2][2]
+        cin, cpi, cout = chans[l - 1], cp[l - 1], chans[l]
+        K = max(64, 4 * cpi)
+        sizes["fwd"][f"down{l}"] = cout * K
+        entries.append(("fwd", f"down{l}", 0, w, cout, 4, cin, cin * 4, 1, 4, K, cpi))
+        sizes["bwd"][f"down{l}"] = K * cout
+        entries.append(("bwd", f"down{l}", 0, w, cin, 4, cout, 4, 1, cin * 4, cout, cpi * cout))
+    for k in range(1, 5):
+        l = 4 - k
+        w = getattr(module, f"upconv{k}").weight                     # [cin][cout][2][2]
+        cin, cout, cpo = chans[l + 1], chans[l], cp[l]
+        N = max(64, 4 * cpo)
+        sizes["fwd"][f"up{k}"] = N * cin
+        entries.append(("fwd", f"up{k}", 0, w, cout, 4, cin, 4, 1, cout * 4, cin, cpo * cin))
+        sizes["bwd"][f"up{k}"] = cin * N
+        entries.append(("bwd", f"up{k}", 0, w, cin, 4, cout, cout * 4, 1, 4, N, cpo))
+        C = chans[l]
+        if C < 64:
+            continue                                                  # the 8-channel gate is one fused vector kernel
+        att = getattr(module, f"att{k}")
+        sizes["fwd"][f"att{k}.w12"] = 2 * C * C                        # [sigmoid_conv; tanh_conv] rows
+        entries.append(("fwd", f"att{k}.w12", 0, att.sigmoid_conv.weight, C, 1, C, C, 0, 1, C, 0))
+        entries.append(("fwd", f"att{k}.w12", C * C, att.tanh_conv.weight, C, 1, C, C, 0, 1, C, 0))
+        sizes["fwd"][f"att{k}.w3"] = C * C
+        entries.append(("fwd", f"att{k}.w3", 0, att.combine_conv.weight, C, 1, C, C, 0, 1, C, 0))
+        sizes["bwd"][f"att{k}.wd"] = C * 3 * C                         # transposed, side by side along K
+        for j, conv in enumerate((att.sigmoid_conv, att.tanh_conv, att.combine_conv)):
+            entries.append(("bwd", f"att{k}.wd", j * C, conv.weight, C, 1, C, 1, 0, C, 3 * C, 0))
+        sizes["bwd"][f"att{k}.wd3"] = C * C
+        entries.append(("bwd", f"att{k}.wd3", 0, att.combine_conv.weight, C, 1, C, 1, 0, C, C, 0))
+    return sizes, entries
+
+
+class PlanPacker(WeightPacker):
+    """WeightPacker over an explicit plan of zero-initialised buffers (several entries may share one)."""
+
+    def __init__(self, module, device, plan):
+        self.device = device
+        self.groups = {}
+        sizes, entries = plan
+        for direction in ("fwd", "bwd"):
+            start, off = {}, 0
+            for key, n in sizes[direction].items():
+                start[key] = off
+                off += (n + 7) // 8 * 8                                # 16-byte aligned operands
+            flat = torch.zeros(off, dtype=torch.bfloat16, device=device)
+            views = {key: flat[start[key]:start[key] + n] for key, n in sizes[direction].items()}
+            mine = [e for e in entries if e[0] == direction]
+            rows = [[p.data_ptr(), flat.data_ptr() + 2 * (start[key] + eoff), N, T, K, 0, sn, st, sk, on, ot]
+                    for (_, key, eoff, p, N, T, K, sn, st, sk, on, ot) in mine]
+            desc = torch.tensor(rows, dtype=torch.int64).to(device)
+            self.groups[direction] = dict(flat=flat, views=views, desc=desc, params=[e[3] for e in mine],
+                                          ptrs=[e[3].data_ptr() for e in mine], versions=None)
+
+
+def lunext_packer_for(module, device):
+    pk = getattr(module, "_packer", None)
+    if pk is None or pk.device != device or not pk.valid_for(module):
+        pk = PlanPacker(module, device, lunext_pack_plan(module))
+        module._packer = pk
+    return pk
+
+
 def packer_for(module, device):
     pk = getattr(module, "_packer", None)
     if pk is None or pk.device != device or not pk.valid_for(module):
