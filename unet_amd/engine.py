@@ -294,9 +294,25 @@ class UNetRun:
         S = _lib.lib.uh_conv_wgrad_splits(B, H, W, C, cin, 9)
         wpart = L.f32(S * C * 9 * cin)
         # the weight gradient and the input gradient both read dy and nothing else of each other: with a second stream
-        # the weight gradient's workgroups can fill CUs that the other kernels leave idle
+        # the weight gradient's workgroups fill CUs that the other kernels leave idle.  The input gradient, which the
+        # rest of backward waits for, is enqueued first so that its workgroups get their CUs first.
         side = self._side_stream()
-        if side is not None:
+        first = side is not None and want_dgrad
+        dx = None
+
+        def dgrad():
+            # dx[m][ci] = sum_t sum_co dy[m + off(t)][co] * W[co][ci][8-t]
+            wd = self.wb[name]
+            out = L.act(B, H, W, cin)
+            self._gemm(B, H, W, dy.ptr, dy.cstride, dy.coff, C, wd.data_ptr(), cin, 9, EPI_MASKED,
+                       out.ptr, out.cstride, out.coff, None, None, None, None, self.masks[lvl].data_ptr(), s)
+            return out
+        if first:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())         # dy is complete here
+            dx = dgrad()                                   # enqueued first: takes the CUs first
+            side.wait_event(ev)
+        elif side is not None:
             side.wait_stream(torch.cuda.current_stream())
         with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
             sw = side.cuda_stream if side is not None else s
@@ -306,13 +322,8 @@ class UNetRun:
             call("uh_wgrad_reduce", wpart.data_ptr(), S, C, 9, cin, 9 * cin, cin, cin * 9, 1, 9, dw.data_ptr(), 0, sw)
         grads[name + ".weight"] = dw
         self._ready(*done)
-        if not want_dgrad:
-            return None
-        # dgrad: dx[m][ci] = sum_t sum_co dy[m + off(t)][co] * W[co][ci][8-t]
-        wd = self.wb[name]
-        dx = L.act(B, H, W, cin)
-        self._gemm(B, H, W, dy.ptr, dy.cstride, dy.coff, C, wd.data_ptr(), cin, 9, EPI_MASKED,
-             dx.ptr, dx.cstride, dx.coff, None, None, None, None, self.masks[lvl].data_ptr(), s)
+        if want_dgrad and dx is None:
+            dx = dgrad()
         return dx
 
     def backward(self, dlogits, grad_alloc=None, on_ready=None):
@@ -379,9 +390,19 @@ class UNetRun:
             S = _lib.lib.uh_conv_wgrad_splits(Bs, Hs, Ws, 4 * w, cin, 1)
             wpart = L.f32(S * 4 * w * cin)
             dw = self._galloc(f"upconv{k}.weight", tuple(up.weight.shape))     # [cin][w][2][2]
+            wd = self.wb[f"upconv{k}"]
+            da = L.act(Bs, Hs, Ws, cin)
+
+            def dgrad():
+                # input gradient: dx[m][ci] = sum_{t,co} d4[m][t*w+co] * W[ci][co][t]
+                self._gemm(Bs, Hs, Ws, d4.ptr, d4.cstride, d4.coff, 4 * w, wd.data_ptr(), cin, 1, EPI_MASKED,
+                           da.ptr, da.cstride, da.coff, None, None, None, None, self.masks[l + 1].data_ptr(), s)
             side = self._side_stream()
-            if side is not None:
-                side.wait_stream(torch.cuda.current_stream())
+            if side is not None:                             # as in _cbr_backward: the input gradient goes first
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                dgrad()
+                side.wait_event(ev)
             with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
                 sw = side.cuda_stream if side is not None else s
                 self._wgrad(Bs, Hs, Ws, d4.ptr, d4.cstride, d4.coff, 4 * w, a_in.ptr, a_in.cstride, a_in.coff,
@@ -389,11 +410,8 @@ class UNetRun:
                 call("uh_wgrad_reduce", wpart.data_ptr(), S, w, 4, cin, cin, w * cin, 4, 1, w * 4, dw.data_ptr(), 0, sw)
             grads[f"upconv{k}.weight"] = dw
             self._ready(f"upconv{k}.weight", f"upconv{k}.bias")
-            # input gradient: dx[m][ci] = sum_{t,co} d4[m][t*w+co] * W[ci][co][t]
-            wd = self.wb[f"upconv{k}"]
-            da = L.act(Bs, Hs, Ws, cin)
-            self._gemm(Bs, Hs, Ws, d4.ptr, d4.cstride, d4.coff, 4 * w, wd.data_ptr(), cin, 1, EPI_MASKED,
-                 da.ptr, da.cstride, da.coff, None, None, None, None, self.masks[l + 1].data_ptr(), s)
+            if side is None:
+                dgrad()
         for l in range(4, -1, -1):                           # bridge, then encoder levels 3..0
             w = WIDTHS[l]
             B, H, W = self.geo[l]
