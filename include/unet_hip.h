@@ -241,6 +241,14 @@ int uh_nchw_to_c8(int B, int Cin, int H, int W, const float* x, void* out, int o
 int uh_adam_step(long long n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2,
                  float eps, float weight_decay, int step, uh_stream s);
 
+/* ---- nn.BCEWithLogitsLoss() as the trainer builds it (trainer/training_utils.py:105: mean reduction, no weights),
+ * forward and backward in one pass over fp32 logits and targets of n elements:
+ *   loss[0] = mean( max(x,0) - x t + log(1 + exp(-|x|)) );  dlogits = grad_scale * (sigmoid(x) - t) / n
+ * (dlogits may be NULL: forward only).  workspace: uh_bce_logits_workspace(n) bytes. */
+size_t uh_bce_logits_workspace(long long n);
+int uh_bce_logits(long long n, const float* logits, const float* targets, float grad_scale, float* loss,
+                  float* dlogits, void* workspace, size_t workspace_bytes, uh_stream s);
+
 /* ---- self-regularisation loss (models/losses.py:6-217; trainer/training_utils.py:100-101,142-143) ------------
  * loss = 0.4*CE + 0.6*Dice + 0.015*(LSRC + LIFD) (losses.py:72).  For one-channel logits the CE term and its
  * gradient are identically zero; LSRC and LIFD enter as constants (losses.py:63-69).

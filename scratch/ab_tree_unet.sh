@@ -1,5 +1,5 @@
 #!/bin/bash
 set -e
 cd $GRAFT_REPO_ROOT
-timeout -k 10 400 python -u -m pytest tests/test_unet_gpu.py tests/test_fullsize_gpu.py -x -q --timeout 200 --timeout-method thread 2>&1 | tail -2
+timeout -k 10 400 python -u -m pytest tests/test_kernels_gpu.py tests/test_unet_gpu.py tests/test_eval_gpu.py -x -q --timeout 200 --timeout-method thread 2>&1 | tail -2
 bash scratch/ab_tree.sh ""

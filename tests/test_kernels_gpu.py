@@ -579,3 +579,24 @@ def test_depthwise_conv_padded_channels():
     with pytest.raises(_lib.HipKernelError):
         call("uh_dwconv3x3_fwd", B, H, W, Cp, xa.ptr, xa.cstride, xa.coff, wd.data_ptr(), Cp + 1, bd.data_ptr(),
              _lib.EPI_RAW_STATS, None, None, mask.data_ptr(), y.ptr, y.cstride, y.coff, stat.data_ptr(), S())
+
+
+@pytest.mark.parametrize("shape", [(32, 1, 256, 256), (3, 1, 17, 33), (1, 1, 1, 1)])
+def test_bce_with_logits_value_and_gradient(shape):
+    """uh_bce_logits against torch's BCEWithLogitsLoss (the reference's criterion, training_utils.py:105) and
+    its autograd gradient, fp32: saturated logits included."""
+    from unet_amd.dp import bce_with_logits
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(shape, generator=g) * 4
+    x.view(-1)[:1] = 90.0
+    if x.numel() > 4:
+        x.view(-1)[1:4] = torch.tensor([-90.0, 0.0, -0.0])
+    t = (torch.rand(shape, generator=g) > 0.5).float()
+    xr = x.clone().double().requires_grad_(True)
+    ref = torch.nn.BCEWithLogitsLoss()(xr, t.double())
+    ref.backward()
+    loss, dx = bce_with_logits(x.to(DEV), t.to(DEV), 0.5)
+    assert loss.dim() == 0
+    assert abs(float(loss) - float(ref.detach())) <= 2e-6 * abs(float(ref.detach())) + 1e-30    # denormal losses may flush
+    # sigmoid(x) - t cancels near saturation: fp32 rounding of the sigmoid (6e-8) is the absolute floor
+    torch.testing.assert_close(dx.cpu(), 0.5 * xr.grad.float(), rtol=1e-5, atol=2e-7 * 0.5 / x.numel())

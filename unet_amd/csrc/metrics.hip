@@ -67,3 +67,57 @@ extern "C" int uh_confusion_counts(int planes, long long n, const float* logits,
     hipLaunchKernelGGL(confusion_kernel<false>, grid, dim3(256), 0, (hipStream_t)s, n, logits, mask, c);
   return uh_check_launch("uh_confusion_counts");
 }
+
+// ---- nn.BCEWithLogitsLoss() (mean reduction; trainer/training_utils.py:105) forward and backward in one pass ------
+//   loss = mean_i( max(x,0) - x t + log(1 + exp(-|x|)) ),   dlogits_i = grad_scale * (sigmoid(x_i) - t_i) / n
+// partial[blocks] holds per-workgroup sums; the second kernel adds them in a fixed order.
+static inline int bce_blocks(long long n) {
+  long long b = (n + 256 * 8 - 1) / (256 * 8);
+  return (int)(b > 1024 ? 1024 : (b < 1 ? 1 : b));
+}
+extern "C" size_t uh_bce_logits_workspace(long long n) { return n > 0 ? (size_t)bce_blocks(n) * sizeof(float) : 0; }
+
+__global__ __launch_bounds__(256) void bce_logits_kernel(long long n, const float* __restrict__ x,
+                                                         const float* __restrict__ t, float gscale,
+                                                         float* __restrict__ dx, float* __restrict__ partial) {
+  float acc = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float v = x[i], y = t[i];
+    const float e = expf(-fabsf(v));
+    acc += fmaxf(v, 0.f) - v * y + log1pf(e);
+    const float sg = v >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+    if (dx) dx[i] = gscale * (sg - y);
+  }
+  __shared__ float red[4];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void bce_logits_finish_kernel(int blocks, double inv_n, const float* __restrict__ partial,
+                                                                float* __restrict__ loss) {
+  __shared__ double red[256];
+  double a = 0.0;
+  for (int i = threadIdx.x; i < blocks; i += 256) a += (double)partial[i];
+  red[threadIdx.x] = a;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = (float)(red[0] * inv_n);
+}
+
+extern "C" int uh_bce_logits(long long n, const float* logits, const float* targets, float grad_scale, float* loss,
+                             float* dlogits, void* workspace, size_t workspace_bytes, uh_stream s) {
+  UH_REQUIRE(n > 0 && logits && targets && loss && workspace, "uh_bce_logits: n=%lld", n);
+  UH_REQUIRE(workspace_bytes >= uh_bce_logits_workspace(n), "uh_bce_logits: workspace of %zu bytes, need %zu",
+             workspace_bytes, uh_bce_logits_workspace(n));
+  const int blocks = bce_blocks(n);
+  hipLaunchKernelGGL(bce_logits_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, n, logits, targets,
+                     (float)((double)grad_scale / (double)n), dlogits, (float*)workspace);
+  hipLaunchKernelGGL(bce_logits_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, blocks, 1.0 / (double)n,
+                     (const float*)workspace, loss);
+  return uh_check_launch("uh_bce_logits");
+}

@@ -155,6 +155,22 @@ class FlatAdam:
         pass                                       # every gradient is overwritten by the next backward pass
 
 
+def bce_with_logits(logits, targets, grad_scale=1.0):
+    """(nn.BCEWithLogitsLoss()(logits, targets), grad_scale * its gradient with respect to the logits) from one
+    kernel pass (uh_bce_logits); fp32 CUDA tensors of equal shape."""
+    x = logits.contiguous().float()
+    t = targets.contiguous().float()
+    n = x.numel()
+    dev = x.device
+    ws_bytes = _lib.lib.uh_bce_logits_workspace(n)
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev)
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    dx = torch.empty_like(x)
+    _lib.call("uh_bce_logits", n, x.data_ptr(), t.data_ptr(), float(grad_scale), loss.data_ptr(), dx.data_ptr(),
+              ws.data_ptr(), ws_bytes, torch.cuda.current_stream().cuda_stream)
+    return loss.view(()), dx
+
+
 class DataParallelTrainer:
     """fwd + loss + bwd (+ bucketed all-reduce) + Adam for one shard per rank."""
 
@@ -167,6 +183,10 @@ class DataParallelTrainer:
         self.rank = dist.get_rank(process_group) if joined else 0
         self.group = process_group
         self.criterion = criterion if criterion is not None else nn.BCEWithLogitsLoss()
+        c = self.criterion
+        # the trainer's default loss (training_utils.py:105) has a one-pass kernel for value and gradient
+        self._fused_bce = (type(c) is nn.BCEWithLogitsLoss and c.reduction == "mean" and c.weight is None
+                           and c.pos_weight is None)
         self.buckets = GradBuckets(model, bucket_bytes)
         self.optimizer = FlatAdam(model, self.buckets, lr=lr)                      # training_utils.py:107
         self.timer = None
@@ -238,9 +258,12 @@ class DataParallelTrainer:
         logits = run.forward().requires_grad_(True)
         # what model(images) would leave behind (a criterion may read it: models/losses.py via training_utils.py:143)
         model.intermediate_features = _Features([run.acts[n] for n in FEATURE_LAYERS], run.lease.pool)
-        loss = self.criterion(logits, masks)
-        # d(mean over ranks of loss)/dlogits: fold the 1/world of gradient averaging into the seed
-        (dlogits,) = torch.autograd.grad(loss / self.world, logits)
+        # d(mean over ranks of loss)/dlogits: the 1/world of gradient averaging is folded into the seed
+        if self._fused_bce and masks.shape == logits.shape:
+            loss, dlogits = bce_with_logits(logits.detach(), masks, 1.0 / self.world)
+        else:
+            loss = self.criterion(logits, masks)
+            (dlogits,) = torch.autograd.grad(loss / self.world, logits)
         run.backward(dlogits, grad_alloc=lambda n, shape: self.buckets.views[n], on_ready=self._on_ready)
         run.release()
         self._run = None
