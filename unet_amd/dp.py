@@ -219,9 +219,16 @@ class DataParallelTrainer:
                 continue
             b["launched"] = True
             if self.collectives:
-                if self._run is not None:
-                    self._run.join_side_stream()         # gradients written on the engine's second stream
-                b["work"] = dist.all_reduce(b["tensor"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                # The bucket's gradients were written on this stream (BatchNorm, biases) and on the engine's second
+                # stream (weight gradients).  The collective is issued from the second stream once that has caught up
+                # with this one, so it is ordered after both and this stream never waits for a weight gradient.
+                side = self._run._side_stream() if self._run is not None else None
+                if side is not None:
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        b["work"] = dist.all_reduce(b["tensor"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                else:
+                    b["work"] = dist.all_reduce(b["tensor"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._adam_for_bucket(i, b)
 
     def _adam_for_bucket(self, i, b):

@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from . import _lib
 from ._lib import call, EPI_RAW_STATS, EPI_AFFINE_RELU, EPI_MASKED, EPI_CONVT
-from .engine import BN_EPS, BN_MOMENTUM, _stream, _SIDE_STREAMS
+from .engine import BN_EPS, BN_MOMENTUM, _stream, side_stream_for
 from .layout import pool_for
 from .packing import lunext_packer_for
 
@@ -231,10 +231,7 @@ class LUNeXtRun:
         if os.environ.get("UNET_AMD_WGRAD_STREAM", "1") == "0":
             yield _stream()
             return
-        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
-        st = _SIDE_STREAMS.get(idx)
-        if st is None:
-            st = _SIDE_STREAMS[idx] = torch.cuda.Stream(device=self.device)
+        st = side_stream_for(self.device)
         self._side_used = st
         st.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(st):
