@@ -93,11 +93,12 @@ class UNetRun:
             self.wf = self.packer.get("fwd", _stream())   # by layer name
 
     # ------------------------------------------------------------------ helpers
-    def _gemm(self, *args):
-        """uh_conv_gemm; with a KernelTimer attached, bracketed by events on the launching stream."""
+    def _gemm(self, *args, whole_tiles=False):
+        """uh_conv_gemm; with a KernelTimer attached, bracketed by events on the launching stream.
+        whole_tiles: no workspace, so the launch is not cut evenly over the CUs (no second kernel for the cut tiles)."""
         B, H, W, K, N, T = args[0], args[1], args[2], args[6], args[8], args[9]
         # one scratch buffer per run serves every 3x3 launch (they are ordered on the stream)
-        need = _lib.lib.uh_conv_gemm_workspace(B, H, W, K, N, T)
+        need = 0 if whole_tiles else _lib.lib.uh_conv_gemm_workspace(B, H, W, K, N, T)
         if need > self._ws_bytes:
             self._ws = self.lease.f32((need + 3) // 4)
             self._ws_bytes = need
@@ -315,8 +316,13 @@ class UNetRun:
             # dx[m][ci] = sum_t sum_co dy[m + off(t)][co] * W[co][ci][8-t]
             wd = self.wb[name]
             out = L.act(B, H, W, cin)
+            # Beside a weight gradient on the second stream, whole tiles per workgroup beat even cuts: the kernel that
+            # finishes the cut tiles waits for CUs the weight gradient holds (85 instead of 16 us), and workgroups that
+            # start late undo the even split anyway (step 14.31 -> 14.12 ms).  Alone on the chip even cuts win, but
+            # the choice does not follow the stream setting: both settings then give bit-identical results.
             self._gemm(B, H, W, dy.ptr, dy.cstride, dy.coff, C, wd.data_ptr(), cin, 9, EPI_MASKED,
-                       out.ptr, out.cstride, out.coff, None, None, None, None, self.masks[lvl].data_ptr(), s)
+                       out.ptr, out.cstride, out.coff, None, None, None, None, self.masks[lvl].data_ptr(), s,
+                       whole_tiles=True)
             return out
         if first:
             ev = torch.cuda.Event()
