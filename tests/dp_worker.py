@@ -1,4 +1,4 @@
-"""Worker of tests/test_dp_gpu.py: one rank of a data-parallel U-Net run whose ranks share one GPU.  RCCL refuses two
+"""Worker of tests/test_dp_two_ranks_gpu.py: one rank of a data-parallel U-Net run whose ranks share one GPU.  RCCL refuses two
 ranks on one device and gloo's own device-tensor path does not complete here, so the collectives are staged through
 host memory: copy to the host on the CURRENT stream (which therefore has to be ordered after every producer of the
 tensor, exactly what RCCL's stream would wait for), gloo on the host copy, copy back on the current stream.
@@ -39,6 +39,8 @@ def staged_broadcast(t, src=0, group=None, async_op=False):
 
 
 def main():
+    import faulthandler
+    faulthandler.dump_traceback_later(40, exit=True)      # a stalled rank ends itself and says where it was
     dist.all_reduce, dist.broadcast = staged_all_reduce, staged_broadcast
     out_dir, steps = sys.argv[1], int(sys.argv[2])
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
