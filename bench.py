@@ -266,9 +266,10 @@ def main():
                          "achieved_one_stream": round(ss["conv_band"]["flops"] / (ss["conv_band"]["ms"] * 1e-3) / 1e12, 1),
                          "note": "achieved/frac: launches as they run in the step (input-gradient launches overlap with "
                                  "weight-gradient kernels on a second stream); achieved_one_stream: same launches alone. "
-                                 "A launch is conv_band_kernel plus, where its tiles are cut evenly over the CUs (12 of the "
-                                 "34), the conv_band_fixup_kernel that finishes the cut tiles: avg_launch_us compares with "
-                                 "rocprofv3's conv_band_kernel average + 12/34 of its conv_band_fixup_kernel average",
+                                 "A launch is conv_band_kernel plus, where its tiles are cut evenly over the CUs (6 forward "
+                                 "layers of the 34 launches), the conv_band_fixup_kernel that finishes the cut tiles: "
+                                 "avg_launch_us compares with rocprofv3's conv_band_kernel average + 6/34 of its "
+                                 "conv_band_fixup_kernel average",
                          "flop_per_launch": round(g["flops"] / g["launches"] / 1e9, 2)},
             "kernels": {k: {"TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1),
                             "ms_per_step": round(v["ms"] / instrumented, 3),
