@@ -190,6 +190,6 @@ def test_self_reg_oracle_matches_reference(golden_dir):
         np.testing.assert_allclose(float(osr.dice_loss(logits.detach(), targets)), want[2], rtol=1e-6, err_msg=name)
         assert float(osr.cross_entropy(logits.detach(), targets)) == 0.0 == want[3]    # one class: identically zero
         loss = osr.self_reg_loss(logits, targets, feats, seeds)
-        np.testing.assert_allclose(float(loss), want[4], rtol=1e-6, err_msg=name)
+        np.testing.assert_allclose(float(loss.detach()), want[4], rtol=1e-6, err_msg=name)
         loss.backward()
         np.testing.assert_allclose(logits.grad.numpy(), dwant, rtol=1e-5, atol=1e-9, err_msg=name)
