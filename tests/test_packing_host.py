@@ -1,0 +1,47 @@
+"""Host-side operand repack plans (unet_amd/packing.py): every entry writes inside its buffer, buffers of one
+direction do not overlap, and the plans cover exactly the layers that run as MFMA GEMMs.  CPU only."""
+import torch
+
+import unet_amd
+from unet_amd import packing
+
+
+def _extent(N, T, K, on, ot):
+    """last element index + 1 that pack(dst[n*on + t*ot + k]) touches"""
+    return (N - 1) * on + (T - 1) * ot + (K - 1) + 1
+
+
+def test_lunext_plan_entries_fit_their_buffers():
+    torch.manual_seed(0)
+    m = unet_amd.LUNeXt(3, 1)
+    sizes, entries = packing.lunext_pack_plan(m)
+    assert set(sizes) == {"fwd", "bwd"}
+    keys = {d: set() for d in sizes}
+    for (d, key, off, p, N, T, K, sn, st, sk, on, ot) in entries:
+        assert key in sizes[d], (d, key)
+        keys[d].add(key)
+        assert off + _extent(N, T, K, on, ot) <= sizes[d][key], (d, key)
+        # the source side stays inside the parameter
+        assert (N - 1) * sn + (T - 1) * st + (K - 1) * sk < p.numel(), (d, key)
+    assert keys["fwd"] == set(sizes["fwd"]) and keys["bwd"] == set(sizes["bwd"])
+    # four strided convolutions, four transposed convolutions, three gates at 64 channels and more
+    assert sum(k.startswith("down") for k in sizes["fwd"]) == 4
+    assert sum(k.startswith("up") for k in sizes["fwd"]) == 4
+    assert sorted(k for k in sizes["fwd"] if k.startswith("att")) == ["att1.w12", "att1.w3", "att2.w12", "att2.w3",
+                                                                      "att3.w12", "att3.w3"]
+    # operands narrower than 64 are padded to 64 rows / columns
+    assert sizes["fwd"]["down1"] == 64 * 64 and sizes["fwd"]["up4"] == 64 * 64
+
+
+def test_unet_plan_covers_every_gemm_layer_once_per_direction():
+    torch.manual_seed(0)
+    m = unet_amd.UNet(3, 1)
+    plan = packing.unet_pack_plan(m)
+    for d in ("fwd", "bwd"):
+        names = [e[1] for e in plan if e[0] == d]
+        assert len(names) == len(set(names)) == 17 + 4            # 3x3 layers but the first, transposed convolutions
+        assert "conv1_1" not in names
+    for (d, name, p, N, T, K, sn, st, sk, on, ot, rev) in plan:
+        assert N * T * K == p.numel(), name
+        assert _extent(N, T, K, on, ot) == N * T * K, name        # dense [N][T][K] operand
+        assert (N - 1) * sn + (T - 1) * st + (K - 1) * sk == p.numel() - 1, name
