@@ -64,6 +64,9 @@ enum {
   UH_EPI_CONVT = 3        /* n = tap*Cout+co: out[(b,2y+tap/2,2x+tap%2)][co] = acc + bias[co]; Cout = min(N/4, o_cstride-o_coff)
                              (weight rows beyond 4*Cout are zero padding and are skipped);
                              out has geometry (B,2H,2W); pad rows of out are written as zero */
+  ,
+  UH_EPI_MASKED_BNBWD = 4 /* uh_conv_gemm_bnbwd only: out as UH_EPI_MASKED, plus the BatchNorm-backward sums of the
+                             layer that consumes out (see there) */
 };
 int uh_conv_gemm(int B, int H, int W,
                  const void* a, int a_cstride, int a_coff, int K,
@@ -83,6 +86,18 @@ int uh_conv_gemm_ws(int B, int H, int W,
                     const float* bias, const float* scale, const float* shift,
                     float* stat_partial, const uint8_t* rowmask,
                     void* workspace, size_t workspace_bytes, uh_stream s);
+/* Input gradient of a 3x3 convolution (T = 9, as uh_conv_gemm with UH_EPI_MASKED and no bias) whose result `out` is
+ * the gradient with respect to relu(bn(y)) of the PRECEDING conv+BatchNorm+ReLU layer (unet.py:99-169: conv x_2 reads
+ * conv x_1's activation).  While a tile of out is still in the accumulators, that layer's BatchNorm-backward sums are
+ * taken from it: with d = out * (y*scale + shift > 0),
+ *   stat_partial[mtile][0][n] = sum_rows d,   stat_partial[mtile][1][n] = sum_rows d * (y - mean) * invstd
+ * (uh_conv_gemm_mtiles(B,H,W,N) rows: what uh_bn_relu_bwd_reduce would compute in a pass of its own, ready for
+ * uh_bn_bwd_finalize).  y: the layer's fp16 conv output (N channels in a window of y_cstride). */
+int uh_conv_gemm_bnbwd(int B, int H, int W, const void* a, int a_cstride, int a_coff, int K, const void* w_packed,
+                       int N, void* out, int o_cstride, int o_coff, const uint8_t* rowmask, const void* y,
+                       int y_cstride, int y_coff, const float* mean, const float* invstd, const float* scale,
+                       const float* shift, float* stat_partial, uh_stream s);
+
 /* number of M tiles (= rows of stat_partial) uh_conv_gemm uses for this problem */
 int uh_conv_gemm_mtiles(int B, int H, int W, int N);
 

@@ -600,3 +600,57 @@ def test_bce_with_logits_value_and_gradient(shape):
     assert abs(float(loss) - float(ref.detach())) <= 2e-6 * abs(float(ref.detach())) + 1e-30    # denormal losses may flush
     # sigmoid(x) - t cancels near saturation: fp32 rounding of the sigmoid (6e-8) is the absolute floor
     torch.testing.assert_close(dx.cpu(), 0.5 * xr.grad.float(), rtol=1e-5, atol=2e-7 * 0.5 / x.numel())
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 16, 16, 64, 64), (1, 8, 8, 128, 64), (2, 4, 8, 64, 128),
+                                            (3, 20, 20, 128, 128), (2, 40, 24, 64, 192)])
+def test_conv_dgrad_with_batchnorm_backward_sums(B, H, W, Cin, Cout):
+    """uh_conv_gemm_bnbwd: the input gradient equals uh_conv_gemm(UH_EPI_MASKED) bit for bit, and the per-tile sums
+    it leaves add up to what uh_bn_relu_bwd_reduce gets from that gradient in a pass of its own (which reads the
+    bf16-rounded gradient; the fused sums come from the fp32 accumulators: agreement to bf16 rounding) and to a
+    double-precision evaluation of the same sums."""
+    g = torch.Generator().manual_seed(23)
+    dy = bf(torch.randn(B, Cout, H, W, generator=g))
+    w = bf(torch.randn(Cout, Cin, 3, 3, generator=g) / 24)
+    y = (torch.randn(B, Cin, H, W, generator=g) * 2 + 0.3).half().float()     # conv output of the preceding layer (fp16)
+    mean, invstd = torch.randn(Cin, generator=g) * 0.2, torch.rand(Cin, generator=g) + 0.5
+    gamma, beta = torch.randn(Cin, generator=g), torch.randn(Cin, generator=g) * 0.3
+    scale = gamma * invstd
+    shift = beta - mean * scale
+    pk = torch.empty(Cin * 9 * Cout, dtype=torch.bfloat16, device=DEV)
+    call("uh_pack_weights", w.to(DEV).data_ptr(), pk.data_ptr(), Cin, 9, Cout, 9, 1, Cin * 9, 9 * Cout, Cout, 1, S())
+    a = act_from(dy)
+    ya = act_from(y, cstride=Cin + 64, coff=64, half=True)                    # y inside a wider buffer
+    mask = rowmask(B, H, W)
+    st = [t.to(DEV) for t in (mean, invstd, scale, shift)]
+    plain, fused = new_act(B, H, W, Cin, DEV), new_act(B, H, W, Cin, DEV)
+    call("uh_conv_gemm", B, H, W, a.ptr, a.cstride, a.coff, Cout, pk.data_ptr(), Cin, 9, _lib.EPI_MASKED,
+         plain.ptr, plain.cstride, plain.coff, None, None, None, None, mask.data_ptr(), S())
+    parts = lib.uh_conv_gemm_mtiles(B, H, W, Cin)
+    fp = torch.full((parts, 2, Cin), float("nan"), device=DEV)
+    call("uh_conv_gemm_bnbwd", B, H, W, a.ptr, a.cstride, a.coff, Cout, pk.data_ptr(), Cin, fused.ptr, fused.cstride,
+         fused.coff, mask.data_ptr(), ya.ptr, ya.cstride, ya.coff, st[0].data_ptr(), st[1].data_ptr(),
+         st[2].data_ptr(), st[3].data_ptr(), fp.data_ptr(), S())
+    rparts = lib.uh_bn_bwd_parts(plain.Mp, Cin)
+    rp = torch.empty(rparts, 2, Cin, device=DEV)
+    call("uh_bn_relu_bwd_reduce", plain.Mp, Cin, plain.ptr, plain.cstride, plain.coff, ya.ptr, ya.cstride, ya.coff,
+         st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(), st[3].data_ptr(), rp.data_ptr(), S())
+    torch.cuda.synchronize()
+    assert torch.equal(plain.buf, fused.buf)
+    pads_are_zero(fused)
+    got, sep = fp.double().sum(0).cpu(), rp.double().sum(0).cpu()
+    assert torch.isfinite(got).all()
+    # double-precision sums from the exact gradient
+    da = F.conv_transpose2d(dy.double(), w.double(), padding=1)
+    c = lambda v: v.double().view(1, -1, 1, 1)                                   # noqa: E731
+    d = da * ((y.double() * c(scale) + c(shift)) > 0)
+    want = torch.stack([d.sum((0, 2, 3)), (d * (y.double() - c(mean)) * c(invstd)).sum((0, 2, 3))])
+    xh = (y.double() - c(mean)) * c(invstd)
+    ref = torch.stack([d.abs().sum((0, 2, 3)), (d * xh).abs().sum((0, 2, 3))]).max(dim=1, keepdim=True).values
+    # an element whose pre-activation y*scale + shift is within fp32 rounding of zero may fall on either side of the
+    # ReLU on the device: its contribution is allowed to be missing or extra
+    z = y.double() * c(scale) + c(shift)
+    edge = (z.abs() < 1e-5 * (1 + (y.double() * c(scale)).abs())).double()
+    slack = torch.stack([(da.abs() * edge).sum((0, 2, 3)), ((da * xh).abs() * edge).sum((0, 2, 3))])
+    assert ((got - want).abs() <= 2e-4 * ref + slack).all(), "fused sums against double precision"
+    assert ((got - sep).abs() <= 4e-3 * ref).all(), "fused sums against the separate pass"

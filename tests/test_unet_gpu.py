@@ -300,3 +300,29 @@ def test_two_stream_step_equals_one_stream_step(monkeypatch):
     for u, v in zip(a[1:4], b[1:4]):
         assert torch.equal(u, v)
     assert a[0][-1] < a[0][0]                      # and it trains
+
+
+def test_fused_batchnorm_backward_sums_give_the_same_step(monkeypatch):
+    """UNET_AMD_FUSE_BN_BWD=1 (BatchNorm-backward sums taken in the input-gradient epilogue, from the fp32
+    accumulators instead of the bf16-rounded gradient): same loss, gradients equal to rounding."""
+    from unet_amd.dp import DataParallelTrainer
+    x, m = ref_cpu.synth_batch(4, 3, 64, 64)
+    x, m = x.to(DEV), m.to(DEV)
+    got = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("UNET_AMD_FUSE_BN_BWD", mode)
+        torch.manual_seed(5)
+        model = unet_amd.UNet(3, 1).to(DEV)
+        tr = DataParallelTrainer(model, lr=1e-3)
+        loss = tr.train_step(x, m, step_optimizer=False).item()
+        torch.cuda.synchronize()
+        got[mode] = (loss, {n: tr.buckets.views[n].clone() for n, _ in model.named_parameters()})
+    assert got["0"][0] == got["1"][0]
+    for n, g0 in got["0"][1].items():
+        g1 = got["1"][1][n]
+        if g0.abs().max().item() == 0:
+            assert g1.abs().max().item() == 0, n
+            continue
+        cos = torch.nn.functional.cosine_similarity(g0.flatten().double(), g1.flatten().double(), dim=0).item()
+        assert cos > 0.999, (n, cos)            # bias gradients are sums with heavy cancellation: the most sensitive
+        assert abs(g1.norm().item() / g0.norm().item() - 1) < 2e-2, n

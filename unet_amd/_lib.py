@@ -32,6 +32,7 @@ SIGNATURES = {
     "uh_conv_gemm": (I, [I, I, I, P, I, I, I, P, I, I, I, P, I, I, P, P, P, P, P, P]),
     "uh_conv_gemm_workspace": (Z, [I, I, I, I, I, I]),
     "uh_conv_gemm_ws": (I, [I, I, I, P, I, I, I, P, I, I, I, P, I, I, P, P, P, P, P, P, Z, P]),
+    "uh_conv_gemm_bnbwd": (I, [I, I, I, P, I, I, I, P, I, P, I, I, P, P, I, I, P, P, P, P, P, P]),
     "uh_conv_gemm_mtiles": (I, [I, I, I, I]),
     "uh_conv_wgrad_splits": (I, [I, I, I, I, I, I]),
     "uh_conv_wgrad_workspace": (Z, [I, I, I, I, I, I]),
@@ -98,7 +99,7 @@ SIGNATURES = {
     "uh_cldice_read_terms": (I, [P, I, I, I, P, P]),
 }
 
-EPI_RAW_STATS, EPI_AFFINE_RELU, EPI_MASKED, EPI_CONVT = 0, 1, 2, 3
+EPI_RAW_STATS, EPI_AFFINE_RELU, EPI_MASKED, EPI_CONVT, EPI_MASKED_BNBWD = 0, 1, 2, 3, 4
 
 
 class HipLibraryMissing(ImportError):

@@ -17,6 +17,11 @@ struct GemmArgs {
   int o_cstride, o_coff, mode;
   int H, W;                            // A geometry (for the transposed-conv scatter)
   int Cout;                            // transposed conv: N = 4*Cout
+  // UH_EPI_MASKED_BNBWD: the consuming layer's fp16 conv output and batch statistics (scale/shift above)
+  const char* ybn;
+  int y_cstride, y_coff;
+  const float* bn_mean;
+  const float* bn_invstd;
 };
 
 // How the work of one launch is cut.  A "unit" is one BM x BN output tile (unit u: M tile u / ntn, N tile

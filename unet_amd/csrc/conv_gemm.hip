@@ -289,6 +289,19 @@ __device__ __forceinline__ void band_epilogue(const GemmArgs& p, const f32x4 (&a
   f32x2 s1[4], s2[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) { s1[j] = f32x2{0.f, 0.f}; s2[j] = f32x2{0.f, 0.f}; }
+  uint2 yraw[4][4];                                         // UH_EPI_MASKED_BNBWD: y of the lane's 16 rows x 4 channels
+  if (MODE == UH_EPI_MASKED_BNBWD) {
+    const long long y_row_bytes = (long long)p.y_cstride * 2;
+    const char* yrow = p.ybn + (long long)(p.y_coff + n0 + ncol) * 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        long long m = mrow0 + i * 16 + e;
+        if (ragged && m >= p.Mp) m = p.Mp - 1;              // masked out below; only the address has to be valid
+        yraw[i][e] = *(const uint2*)(yrow + m * y_row_bytes);
+      }
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     uint32_t fl = fw[i];
@@ -331,7 +344,35 @@ __device__ __forceinline__ void band_epilogue(const GemmArgs& p, const f32x4 (&a
       }
     }
   }
-  if (MODE == UH_EPI_RAW_STATS) {
+  if (MODE == UH_EPI_MASKED_BNBWD) {
+    // Second pass over the accumulators, after all stores of the tile have been issued (they cover the latency of
+    // the y loads): d = out * (y*scale + shift > 0); sums of d and of d * xhat per column.
+    const f32x4 sc4 = *(const f32x4*)(p.scale + n0 + ncol), sh4 = *(const f32x4*)(p.shift + n0 + ncol);
+    const f32x4 mu4 = *(const f32x4*)(p.bn_mean + n0 + ncol), is4 = *(const f32x4*)(p.bn_invstd + n0 + ncol);
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint32_t fl = fw[i];
+      if (ragged) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (mrow0 + i * 16 + e >= p.Mp) fl &= ~(0xffu << (8 * e));
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float f = (float)((fl >> (8 * e)) & 0xffu);
+        const h4 yv = *reinterpret_cast<const h4*>(&yraw[i][e]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float yy = (float)yv[j];
+          const float d = (yy * sc4[j] + sh4[j] > 0.f) ? acc[i][j][e] * f : 0.f;
+          s1[j][e & 1] += d;
+          s2[j][e & 1] += d * ((yy - mu4[j]) * is4[j]);
+        }
+      }
+    }
+  }
+  if (MODE == UH_EPI_RAW_STATS || MODE == UH_EPI_MASKED_BNBWD) {
     float t1[4], t2[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -520,7 +561,7 @@ __global__ __launch_bounds__(512) void conv_band_kernel(GemmArgs p, BandSched sc
             if (has_slot5) issue(5, buf1, offA, offB);
           }
         } else if (kx == 1) {
-          if (MODE == UH_EPI_RAW_STATS && c == 0 && pend_mt >= 0) {
+          if ((MODE == UH_EPI_RAW_STATS || MODE == UH_EPI_MASKED_BNBWD) && c == 0 && pend_mt >= 0) {
             band_flush_stats<BM, BN>(p, red, pend_mt, pend_nt, tid);
             pend_mt = -1;
           }
@@ -558,7 +599,7 @@ __global__ __launch_bounds__(512) void conv_band_kernel(GemmArgs p, BandSched sc
 #pragma unroll
       for (int ii = 0; ii < 4; ++ii) fw[ii] = *(const uint32_t*)(smem + C::FLAG_OFF + wave * 256 + (ii * 4 + g) * 4);
       band_epilogue<BM, BN, MODE>(p, acc, mt, nt, fw, wm, wn, l15, g, red);
-      if (MODE == UH_EPI_RAW_STATS) { pend_mt = mt; pend_nt = nt; }
+      if (MODE == UH_EPI_RAW_STATS || MODE == UH_EPI_MASKED_BNBWD) { pend_mt = mt; pend_nt = nt; }
     } else {
       // a piece of a unit: park the accumulators for conv_band_fixup_kernel
       f32x4* slot = (f32x4*)sc.ws + ((long long)(2 * pos + (it_a > 0 ? 0 : 1)) * 16) * 512 + tid;
@@ -571,7 +612,7 @@ __global__ __launch_bounds__(512) void conv_band_kernel(GemmArgs p, BandSched sc
     it_a = 0;
   }
   if (wave < 4) __builtin_amdgcn_s_barrier();   // match the second half's extra barrier
-  if (MODE == UH_EPI_RAW_STATS && pend_mt >= 0) {
+  if ((MODE == UH_EPI_RAW_STATS || MODE == UH_EPI_MASKED_BNBWD) && pend_mt >= 0) {
     __syncthreads();
     band_flush_stats<BM, BN>(p, red, pend_mt, pend_nt, tid);
   }
@@ -618,7 +659,7 @@ __global__ __launch_bounds__(512) void conv_band_fixup_kernel(GemmArgs p, BandSc
     fw[ii] = *(const uint32_t*)(p.rowmask + 4 * d);
   }
   band_epilogue<BM, BN, MODE>(p, acc, mt, nt, fw, wm, wn, l15, g, red);
-  if (MODE == UH_EPI_RAW_STATS) {
+  if (MODE == UH_EPI_RAW_STATS || MODE == UH_EPI_MASKED_BNBWD) {
     __syncthreads();
     band_flush_stats<BM, BN>(p, red, mt, nt, tid);
   }
@@ -664,6 +705,7 @@ static void launch_band(const GemmArgs& p, void* ws, size_t ws_bytes, hipStream_
   sc.aligned = (ws == nullptr || ws_bytes < band_workspace_bytes<BM, BN>(p.Mp, p.N, p.K) || !wasteful) ? 1 : 0;
   if (p.mode == UH_EPI_RAW_STATS) launch_band_mode<BM, BN, UH_EPI_RAW_STATS>(p, sc, st);
   else if (p.mode == UH_EPI_AFFINE_RELU) launch_band_mode<BM, BN, UH_EPI_AFFINE_RELU>(p, sc, st);
+  else if (p.mode == UH_EPI_MASKED_BNBWD) launch_band_mode<BM, BN, UH_EPI_MASKED_BNBWD>(p, sc, st);
   else launch_band_mode<BM, BN, UH_EPI_MASKED>(p, sc, st);
 }
 
@@ -760,6 +802,9 @@ extern "C" int uh_conv_gemm_ws(int B, int H, int W, const void* a, int a_cstride
   p.W = W;
   // transposed conv: Cout = N/4, or the width of the output window when that is narrower (N zero-padded to 64)
   p.Cout = (mode == UH_EPI_CONVT) ? ((N / 4 < o_cstride - o_coff) ? N / 4 : o_cstride - o_coff) : N;
+  p.ybn = nullptr;
+  p.y_cstride = p.y_coff = 0;
+  p.bn_mean = p.bn_invstd = nullptr;
   hipStream_t st = (hipStream_t)s;
   if (T == 9) {
     UH_REQUIRE(((uintptr_t)workspace & 15) == 0, "conv_gemm: workspace must be 16-byte aligned");
@@ -773,4 +818,52 @@ extern "C" int uh_conv_gemm_ws(int B, int H, int W, const void* a, int a_cstride
     launch_tile<128, 128>(p, st);
   }
   return uh_check_launch("conv_gemm");
+}
+
+extern "C" int uh_conv_gemm_bnbwd(int B, int H, int W, const void* a, int a_cstride, int a_coff, int K,
+                                  const void* w_packed, int N, void* out, int o_cstride, int o_coff,
+                                  const uint8_t* rowmask, const void* y, int y_cstride, int y_coff, const float* mean,
+                                  const float* invstd, const float* scale, const float* shift, float* stat_partial,
+                                  uh_stream s) {
+  UH_REQUIRE(B > 0 && H > 0 && W > 0, "conv_gemm_bnbwd: bad geometry B=%d H=%d W=%d", B, H, W);
+  UH_REQUIRE(K > 0 && K % 64 == 0 && N > 0 && N % 64 == 0, "conv_gemm_bnbwd: K=%d N=%d must be multiples of 64", K, N);
+  UH_REQUIRE(a && w_packed && out && rowmask && y && mean && invstd && scale && shift && stat_partial,
+             "conv_gemm_bnbwd: null pointer");
+  UH_REQUIRE(a_cstride >= a_coff + K && a_cstride % 8 == 0 && a_coff % 8 == 0, "conv_gemm_bnbwd: bad A view");
+  UH_REQUIRE(o_cstride >= o_coff + N && o_cstride % 8 == 0 && o_coff % 8 == 0, "conv_gemm_bnbwd: bad out view");
+  UH_REQUIRE(y_cstride >= y_coff + N && y_cstride % 4 == 0 && y_coff % 4 == 0, "conv_gemm_bnbwd: bad y view");
+  GemmArgs p;
+  p.A = (const char*)a;
+  p.Wt = (const char*)w_packed;
+  p.out = (char*)out;
+  p.bias = nullptr;
+  p.scale = scale;
+  p.shift = shift;
+  p.stat_partial = stat_partial;
+  p.rowmask = rowmask;
+  p.Mp = uh_mp(B, H, W);
+  p.a_cstride = a_cstride;
+  p.a_coff = a_coff;
+  p.K = K;
+  p.N = N;
+  p.T = 9;
+  p.KC = K / 64;
+  p.Wp = W + 1;
+  p.o_cstride = o_cstride;
+  p.o_coff = o_coff;
+  p.mode = UH_EPI_MASKED_BNBWD;
+  p.H = H;
+  p.W = W;
+  p.Cout = N;
+  p.ybn = (const char*)y;
+  p.y_cstride = y_cstride;
+  p.y_coff = y_coff;
+  p.bn_mean = mean;
+  p.bn_invstd = invstd;
+  hipStream_t st = (hipStream_t)s;
+  if (use_wide_m(N))
+    launch_band<512, 64>(p, nullptr, 0, st);
+  else
+    launch_band<256, 128>(p, nullptr, 0, st);
+  return uh_check_launch("conv_gemm_bnbwd");
 }

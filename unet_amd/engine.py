@@ -20,6 +20,14 @@ BN_MOMENTUM = 0.1
 WIDTHS = (64, 128, 256, 512, 1024)
 
 
+# UNET_AMD_FUSE_BN_BWD=1: BatchNorm-backward sums are taken in the epilogue of the input gradient that produces the
+# tensor they are sums of (uh_conv_gemm_bnbwd) instead of in a pass of their own (uh_bn_relu_bwd_reduce).  Off by
+# default: measured on the training step (batch 32, 256^2) the nine passes it saves and the longer epilogue cancel
+# (14.03 against 14.06 ms; the 3x3 kernel drops from 904 to 853 TFLOP/s in the step) -- the epilogue waits for the
+# layer's fp16 conv output, and loads that return in order cannot stay in flight across the main loop's staging waits.
+def fuse_bn_bwd():
+    return os.environ.get("UNET_AMD_FUSE_BN_BWD", "0") == "1"
+
 _SIDE_STREAMS = {}
 
 
@@ -75,6 +83,7 @@ class UNetRun:
         # set by a caller whose grad_alloc hands out the same memory every step and never writes to it: the gradients
         # that are identically zero (conv biases in front of train-mode BatchNorm) then need no fill after the first step
         self.zero_grads_kept = False
+        self._fused_stats = {}     # layer name -> (partial, parts) left by the input gradient that feeds it
         self.timer = None          # optional KernelTimer (bench): times selected kernel launches with events
         self._ws, self._ws_bytes = None, 0
         self.packer = packer_for(module, x.device)
@@ -261,7 +270,7 @@ class UNetRun:
         if self.on_ready is not None:
             self.on_ready(names)
 
-    def _cbr_backward(self, name, lvl, da, grads, want_dgrad=True):
+    def _cbr_backward(self, name, lvl, da, grads, want_dgrad=True, stats_for=None):
         """Backward of conv3x3+BN+ReLU.  `da` = gradient w.r.t. the layer's activated output.
         Returns the gradient w.r.t. the layer's input activation (an Act with a_in's channel count)."""
         rec = self.recs[name]
@@ -272,11 +281,15 @@ class UNetRun:
         y = rec.y
         Mp = y.Mp
         bnname = name.replace("conv", "bn", 1)
-        parts = _lib.lib.uh_bn_bwd_parts(Mp, C)
-        partial = L.f32(parts * 2 * C)
-        call("uh_bn_relu_bwd_reduce", Mp, C, da.ptr, da.cstride, da.coff, y.ptr, y.cstride, y.coff,
-             rec.mean.data_ptr(), rec.invstd.data_ptr(), rec.scale.data_ptr(), rec.shift.data_ptr(),
-             partial.data_ptr(), s)
+        fused = self._fused_stats.pop(name, None)
+        if fused is not None:                      # the input gradient that produced da left the sums behind
+            partial, parts = fused
+        else:
+            parts = _lib.lib.uh_bn_bwd_parts(Mp, C)
+            partial = L.f32(parts * 2 * C)
+            call("uh_bn_relu_bwd_reduce", Mp, C, da.ptr, da.cstride, da.coff, y.ptr, y.cstride, y.coff,
+                 rec.mean.data_ptr(), rec.invstd.data_ptr(), rec.scale.data_ptr(), rec.shift.data_ptr(),
+                 partial.data_ptr(), s)
         dgamma = self._galloc(bnname + ".weight", (C,))
         dbeta = self._galloc(bnname + ".bias", (C,))
         coef = L.f32(2 * C)
@@ -320,6 +333,22 @@ class UNetRun:
             # finishes the cut tiles waits for CUs the weight gradient holds (85 instead of 16 us), and workgroups that
             # start late undo the even split anyway (step 14.31 -> 14.12 ms).  Alone on the chip even cuts win, but
             # the choice does not follow the stream setting: both settings then give bit-identical results.
+            prev = self.recs.get(stats_for) if stats_for else None
+            if prev is not None and fuse_bn_bwd() and prev.cout == cin:
+                # `out` is the gradient at the output of layer `stats_for` (conv + BatchNorm + ReLU): its
+                # BatchNorm-backward sums are taken while the tiles are still in the accumulators
+                parts = _lib.lib.uh_conv_gemm_mtiles(B, H, W, cin)
+                partial = L.f32(parts * 2 * cin)
+                args = (B, H, W, dy.ptr, dy.cstride, dy.coff, C, wd.data_ptr(), cin, out.ptr, out.cstride, out.coff,
+                        self.masks[lvl].data_ptr(), prev.y.ptr, prev.y.cstride, prev.y.coff, prev.mean.data_ptr(),
+                        prev.invstd.data_ptr(), prev.scale.data_ptr(), prev.shift.data_ptr(), partial.data_ptr(), s)
+                if self.timer is None:
+                    call("uh_conv_gemm_bnbwd", *args)
+                else:
+                    with self.timer.launch("conv_band", 2.0 * B * H * W * C * cin * 9):
+                        call("uh_conv_gemm_bnbwd", *args)
+                self._fused_stats[stats_for] = (partial, parts)
+                return out
             self._gemm(B, H, W, dy.ptr, dy.cstride, dy.coff, C, wd.data_ptr(), cin, 9, EPI_MASKED,
                        out.ptr, out.cstride, out.coff, None, None, None, None, self.masks[lvl].data_ptr(), s,
                        whole_tiles=True)
@@ -381,7 +410,7 @@ class UNetRun:
             l = 4 - k
             w = WIDTHS[l]
             B, H, W = self.geo[l]
-            da = self._cbr_backward(f"conv_up{k}_2", l, da, grads)
+            da = self._cbr_backward(f"conv_up{k}_2", l, da, grads, stats_for=f"conv_up{k}_1")
             dcat = self._cbr_backward(f"conv_up{k}_1", l, da, grads)     # [Mp][2w]
             skip_grads[l] = dcat.window(0, w)
             dup = dcat.window(w, w)
@@ -439,7 +468,7 @@ class UNetRun:
                 call("uh_maxpool2_bwd", B, H, W, w, a2.ptr, a2.cstride, a2.coff, da.ptr, da.cstride, da.coff,
                      sg.ptr, sg.cstride, sg.coff, dsum.ptr, dsum.cstride, dsum.coff, s)
                 da = dsum
-            da = self._cbr_backward(f"conv{l + 1}_2", l, da, grads)
+            da = self._cbr_backward(f"conv{l + 1}_2", l, da, grads, stats_for=f"conv{l + 1}_1")
             da = self._cbr_backward(f"conv{l + 1}_1", l, da, grads, want_dgrad=(l > 0))
         self.join_side_stream()
         return grads
