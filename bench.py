@@ -156,7 +156,7 @@ def main():
         # RCCL's streams take hardware queues too: with the default of 4 per process the step's two streams can end up
         # on one queue (measured with a one-rank group: 14.9 ms per step against 14.1 ms with 8 queues).  Must be set
         # before the HIP runtime starts.
-        if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 8:
+        if os.environ.get("UNET_AMD_BENCH_HWQ8", "1") == "1" and int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 8:
             os.environ["GPU_MAX_HW_QUEUES"] = "8"
         # RCCL prints a version banner on stdout when its communicator comes up; the contract is ONE JSON line there
         sys.stdout.flush()

@@ -19,40 +19,58 @@ def golden_dir():
     return GOLDEN
 
 
+def gpu_present():
+    """True on a machine with a GPU, WITHOUT starting the HIP runtime in this process: counting devices does not
+    open a context (torch.cuda.is_available() does)."""
+    if not os.path.exists("/dev/kfd"):
+        return False
+    try:
+        import torch
+        return torch.cuda.device_count() > 0
+    except Exception:
+        return False
+
+
 # ---- two data-parallel ranks on the one GPU of the test box ----------------------------------------------------------
-# On this box a rank stalls inside a device copy as soon as a THIRD process holds a context on the same GPU (seen with
-# an unrelated idle process as well as with a pytest process that has loaded the kernel library).  The two-rank run of
-# tests/test_dp_two_ranks_gpu.py therefore happens here, at session start, before any test module (and with it the
-# kernel library) has been imported into the pytest process; the test then checks what the ranks left behind.
-def run_two_ranks(out_dir, steps=3, world=2, port=29531):
+# tests/test_dp_two_ranks_gpu.py checks what two ranks of tests/dp_worker.py leave behind.  The ranks run from
+# pytest_collection_modifyitems, i.e. only when that test was selected, and this process does not open a GPU context
+# before they have finished (test modules look for a GPU with gpu_present(), not torch.cuda.is_available()).
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def run_two_ranks(out_dir, steps=3, world=2):
     import subprocess
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dp_worker.py"),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dp_worker.py"),
            str(out_dir), str(steps)]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     try:
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=100)
-    except subprocess.TimeoutExpired:
-        return dict(out_dir=str(out_dir), steps=steps, world=world, returncode=None, log="timed out after 100 s")
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=150)
+    except subprocess.TimeoutExpired as e:
+        return dict(out_dir=str(out_dir), steps=steps, world=world, returncode=None,
+                    log="timed out after 150 s\n" + str(e.stdout)[-2000:] + str(e.stderr)[-3000:])
     return dict(out_dir=str(out_dir), steps=steps, world=world, returncode=r.returncode,
-                log=r.stdout[-2000:] + r.stderr[-4000:])
+                log=r.stdout[-3000:] + r.stderr[-4000:])
 
 
-def pytest_sessionstart(session):
-    session.config._dp_two_ranks = None
-    expr = session.config.getoption("markexpr", "") or ""
-    names = [str(a) for a in session.config.args]
-    if "not gpu" in expr or (any(n.endswith(".py") or "::" in n for n in names)
-                             and not any("test_dp_two_ranks_gpu" in n for n in names)):
-        return                                   # the GPU tests, or this one, were not asked for
-    try:
-        import torch
-        if not torch.cuda.is_available():
-            return
-    except Exception:
+def pytest_collection_modifyitems(config, items):
+    config._dp_two_ranks = None
+    if not any("test_dp_two_ranks_gpu" in it.nodeid for it in items) or not gpu_present():
         return
     import tempfile
-    session.config._dp_two_ranks = run_two_ranks(tempfile.mkdtemp(prefix="dp_two_ranks_"))
+    config._dp_tmp = tempfile.mkdtemp(prefix="dp_two_ranks_")
+    config._dp_two_ranks = run_two_ranks(config._dp_tmp)
+
+
+def pytest_unconfigure(config):
+    tmp = getattr(config, "_dp_tmp", None)
+    if tmp:
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 @pytest.fixture

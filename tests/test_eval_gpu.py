@@ -17,7 +17,9 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-if not torch.cuda.is_available():
+from conftest import gpu_present            # noqa: E402
+
+if not gpu_present():
     pytest.skip("needs a GPU", allow_module_level=True)
 
 import unet_amd                                        # noqa: E402

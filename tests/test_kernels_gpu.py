@@ -8,7 +8,9 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-if not torch.cuda.is_available():
+from conftest import gpu_present            # noqa: E402
+
+if not gpu_present():
     pytest.skip("needs a GPU", allow_module_level=True)
 
 from unet_amd import _lib                    # noqa: E402

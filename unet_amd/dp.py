@@ -21,7 +21,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from . import _lib
-from .engine import UNetRun
+from .engine import UNetRun, side_stream_for
 from .unet import _Features, FEATURE_LAYERS
 
 
@@ -196,6 +196,10 @@ class DataParallelTrainer:
         # UNET_AMD_FORCE_COLLECTIVES=1 runs the broadcasts and all-reduces with a single rank too (a rehearsal
         # of the RCCL calls on a one-GPU machine)
         self.collectives = joined and (self.world > 1 or os.environ.get("UNET_AMD_FORCE_COLLECTIVES") == "1")
+        # the second stream takes its hardware queue before the process group's streams take theirs
+        dev = next(model.parameters()).device
+        if dev.type == "cuda":
+            side_stream_for(dev)
         if self.collectives:
             # same initial weights on every rank
             for p in model.parameters():

@@ -32,16 +32,25 @@ _SIDE_STREAMS = {}
 
 
 def side_stream_for(device):
-    """The second stream of a device (one per process and device).  It is created with high priority: that gives it a
-    hardware queue of its own.  A process has few hardware queues (GPU_MAX_HW_QUEUES, 4 by default) and HIP deals
-    streams onto them in turn; once a process group has made its own streams, a normal-priority second stream was
-    observed to share the queue of the main stream, which serialises the two (training step 15.2 ms instead of
-    14.4 ms).  Which of the two streams' kernels go first makes no measurable difference."""
+    """The second stream of a device (one per process and device).
+
+    It should own a hardware queue.  A process has few hardware queues (GPU_MAX_HW_QUEUES, 4 by default) and HIP binds a
+    stream to one of them, in turn, when the stream is first used; a second stream first used after a process group
+    had made its streams was observed on the main stream's queue, which serialises the two (training step 15.2 instead of
+    14.4 ms).  So the stream is used once right here, at creation, and the data-parallel trainer creates it before its
+    first collective.  UNET_AMD_SIDE_PRIORITY picks its priority (default 0, normal).  High priority (-1) also gets a
+    queue of its own, but then the queue whose head is a wait for an event of the main stream outranks the main
+    stream's queue: when both were placed on one hardware pipe (seen when two processes shared a GPU) the main queue
+    was not served any more and the step never finished."""
     device = torch.device(device)
     idx = device.index if device.index is not None else torch.cuda.current_device()
     st = _SIDE_STREAMS.get(idx)
     if st is None:
-        st = _SIDE_STREAMS[idx] = torch.cuda.Stream(device=torch.device("cuda", idx), priority=-1)
+        prio = int(os.environ.get("UNET_AMD_SIDE_PRIORITY", "0"))
+        st = _SIDE_STREAMS[idx] = torch.cuda.Stream(device=torch.device("cuda", idx), priority=prio)
+        with torch.cuda.stream(st):
+            torch.zeros(1, device=torch.device("cuda", idx))      # first use: binds the hardware queue now
+        st.synchronize()
     return st
 
 
