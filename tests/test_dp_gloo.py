@@ -146,3 +146,48 @@ def test_grad_averager_world2_with_unused_parameters(tmp_path):
             assert torch.allclose(r[0]["mean"][n], want, rtol=1e-6, atol=1e-8), n
             assert torch.equal(r[0]["mean"][n], r[1]["mean"][n]), n
             assert not torch.equal(r[0]["local"][n], r[1]["local"][n]), n   # the shards really differed
+
+
+def test_shards_have_equal_length_when_items_do_not_divide():
+    """97 items over 2 ranks, batch 16: 49 + 48 samples would be 4 steps on one rank and 3 on the other."""
+    from unet_amd.dp import DataParallelTrainer
+    for n, world in ((97, 2), (5, 4), (8, 8), (3, 8), (1, 2)):
+        shards = [DataParallelTrainer.shard(n, epoch=3, rank=r, world=world, seed=1) for r in range(world)]
+        assert len({len(s) for s in shards}) == 1, (n, world, [len(s) for s in shards])
+        assert set(torch.cat(shards).tolist()) == set(range(n))          # every item is still seen
+        assert len(torch.cat(shards)) == -(-n // world) * world
+    assert len(DataParallelTrainer.shard(96, 0, 0, 2)) == 48 and len(DataParallelTrainer.shard(0, 0, 0, 2)) == 0
+
+
+def _fit_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from unet_amd import trainer
+    lr = [1e-3]
+    sched = trainer.PlateauLR(lambda: lr[0], lambda v: lr.__setitem__(0, v), patience=1, factor=0.5)
+    # per-replica validation losses that would stop rank 1 two epochs before rank 0
+    local = {0: [1.0, 0.9, 0.8, 0.7, 0.71, 0.72, 0.73, 0.74], 1: [1.0, 0.9, 0.91, 0.92, 0.93, 0.6, 0.5, 0.4]}[rank]
+    steps = []
+
+    def train_epoch(epoch):
+        t = torch.ones(1)
+        dist.all_reduce(t)                         # stands for the step's gradient all-reduce: needs every rank
+        steps.append(epoch)
+        return 0.0
+    saved = []
+    tr, va, best = trainer.fit_loop(len(local), 3, train_epoch, lambda e: local[e], sched, lambda: saved.append(len(steps)),
+                                    log=lambda *_: None, agree=trainer.rank0_value)
+    torch.save({"epochs": len(steps), "lr": lr[0], "val": va, "best": best, "saved": saved},
+               os.path.join(out_dir, f"fit{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_fit_loop_decisions_agree_across_ranks(tmp_path):
+    """learning-rate schedule, best checkpoint and early stop follow rank 0's validation loss on every rank"""
+    world = 2
+    mp.spawn(_fit_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(os.path.join(tmp_path, f"fit{i}.pt"), weights_only=True) for i in range(world)]
+    assert r[0] == r[1]
+    assert r[0]["epochs"] == 7 and r[0]["best"] == 0.7 and r[0]["lr"] == 5e-4

@@ -209,9 +209,15 @@ class DataParallelTrainer:
 
     @staticmethod
     def shard(n_items, epoch, rank, world, seed=0):
-        """indices of this rank's shard of a shuffled epoch (same permutation on every rank)."""
+        """indices of this rank's shard of a shuffled epoch (same permutation on every rank).  Every rank gets the same
+        number of indices: when n_items is not a multiple of world the permutation is extended with its own first
+        entries (as torch's DistributedSampler does), so that all ranks run the same number of steps with equal batch
+        sizes and every collective of a step has all its participants."""
         g = torch.Generator().manual_seed(seed + epoch)
         perm = torch.randperm(n_items, generator=g)
+        pad = (-n_items) % world
+        if pad and n_items > 0:
+            perm = torch.cat([perm, perm[torch.arange(pad) % n_items]])
         return perm[rank::world]
 
     def _on_ready(self, names):

@@ -55,15 +55,31 @@ class PlateauLR:
             self.num_bad_epochs = 0
 
 
-def fit_loop(epochs, patience, train_epoch, validate, scheduler, save_best, log=print, model_type="UNet", get_lr=None):
+def rank0_value(value, group=None):
+    """`value` (a float) as rank 0 holds it, on every rank of the process group; the value itself without a group."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return value
+    box = [value]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    return box[0]
+
+
+def fit_loop(epochs, patience, train_epoch, validate, scheduler, save_best, log=print, model_type="UNet", get_lr=None,
+             agree=None):
     """The epoch loop of training_utils.py:125-242: train, validate, scheduler.step(val), keep the best
-    checkpoint, stop after `patience` epochs without a new best.  Returns (train_losses, val_losses, best)."""
+    checkpoint, stop after `patience` epochs without a new best.  Returns (train_losses, val_losses, best).
+    agree(value) -> value: in data-parallel training every decision below (learning-rate schedule, best checkpoint,
+    early stop) must fall the same way on every rank, or the ranks stop meeting in their collectives; `agree` replaces
+    the local validation loss by one all ranks share (rank 0's)."""
     train_losses, val_losses = [], []
     best_val_loss, patience_counter = float("inf"), 0
     for epoch in range(epochs):
         avg_train_loss = train_epoch(epoch)
         train_losses.append(avg_train_loss)
         avg_val_loss = validate(epoch)
+        if agree is not None:
+            avg_val_loss = agree(avg_val_loss)
         val_losses.append(avg_val_loss)
         scheduler.step(avg_val_loss)
         log(f"Epoch {epoch + 1}/{epochs}:")
@@ -255,6 +271,11 @@ def train_model(train_data, validation_data, model_type="UNet", epochs=50, batch
         return total.item() / max(n_batches, 1)
 
     def validate(epoch):
+        if world > 1:
+            # BatchNorm statistics are per replica (as under DistributedDataParallel): validate with rank 0's on every
+            # rank, so that all ranks judge the same model (it is also the one rank 0 saves as the best checkpoint)
+            for b in model.buffers():
+                torch.distributed.broadcast(b.data, src=0)
         model.eval()
         total = torch.zeros((), dtype=torch.float64, device=dev)
         n_batches = 0
@@ -270,7 +291,7 @@ def train_model(train_data, validation_data, model_type="UNet", epochs=50, batch
             torch.save({k: v.detach().clone() for k, v in model.state_dict().items()}, save_path)
 
     _, _, best = fit_loop(epochs, patience, train_epoch, validate, scheduler, save_best, log=log,
-                          model_type=model_type, get_lr=get_lr)
+                          model_type=model_type, get_lr=get_lr, agree=rank0_value if world > 1 else None)
     if world > 1:
         torch.distributed.barrier()
     model.load_state_dict(torch.load(save_path, map_location=dev, weights_only=True))
