@@ -1,16 +1,11 @@
 #!/bin/bash
-# rocprofv3 passes for the committed profile summaries (run on the GPU box from the repo root)
-set -e
-R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/prof_r01
-mkdir -p $O
+# prof_round.sh <tag>: bench line + rocprofv3 kernel stats of the same command -> gpurun_out/prof_<tag>/
+tag=$1; out=gpurun_out/prof_$tag; mkdir -p $out
+timeout -k 10 300 python bench.py --steps 20 --warmup 5 > $out/bench_unet.json 2> $out/bench_unet.err || exit 1
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats -o unet --output-format csv -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err
-timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o unet --output-format csv -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2> $O/fetch.err
-timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $O/write -o unet --output-format csv -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2> $O/write.err
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats_lunext -o lunext --output-format csv -- python $R/bench.py --workload lunext --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_lunext_under_rocprof.json 2> $O/stats_lunext.err
-cd $R
-timeout -k 10 300 python bench.py --workload lunext > $O/bench_lunext.json 2> $O/bench_lunext.err
-timeout -k 10 300 python bench.py > $O/bench_unet.json 2> $O/bench_unet.err
-cat $O/bench_lunext.json $O/bench_unet.json
-ls $O/*
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/rp -o unet -- python3 $GRAFT_REPO_ROOT/bench.py --steps 16 --warmup 4 --no-cpu-baseline > $GRAFT_REPO_ROOT/$out/bench_unet_under_rocprof.json 2> $GRAFT_REPO_ROOT/$out/rocprof.err || exit 1
+cd $GRAFT_REPO_ROOT
+f=$(find $out/rp -name "*kernel_stats.csv" | head -1); cp $f $out/unet_kernel_stats.csv
+find $out/rp -name "*.csv" ! -name "*kernel_stats.csv" -delete; find $out/rp -name "*.db" -delete
+head -30 $out/unet_kernel_stats.csv | cut -c1-150
+python -c "import json; d=json.load(open('$out/bench_unet.json')); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['kernels'])"

@@ -8,8 +8,9 @@ A rank whose device work does not complete within STALL_SECONDS does not sit in 
 first kernel launch that has not completed ("STALL ..." lines) and exits with status 3, so a stall names the launch
 it is behind.
 
-Environment switches (diagnosis): DP_WORKER_SIDE_PRIORITY=0 gives the second stream normal priority;
-DP_WORKER_TRACE=0 turns the per-launch events off."""
+Environment switches (diagnosis): UNET_AMD_SIDE_PRIORITY=-1 gives the second stream high priority (the setting under
+which the ranks stalled); DP_WORKER_PAGEABLE=1 stages through pageable memory; DP_WORKER_TRACE=0 turns the per-launch
+events off."""
 import os
 import sys
 import time
@@ -136,8 +137,6 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
-    if os.environ.get("DP_WORKER_SIDE_PRIORITY") == "0":
-        engine._SIDE_STREAMS[0] = torch.cuda.Stream(device=dev, priority=0)
     if os.environ.get("DP_WORKER_TRACE", "1") != "0":
         _lib.call = engine.call = _traced_call
     dist.init_process_group("gloo")

@@ -24,8 +24,16 @@ from .layout import mp_rows, new_act
 
 def reference_seed(idx):
     """losses.py:126.  Python salts string hashes per process unless PYTHONHASHSEED is set, so this value --
-    like the reference's -- is fixed within a process only."""
+    like the reference's -- is fixed within a process only.  Pass it as `seed_of` to reproduce a reference run made
+    under a fixed PYTHONHASHSEED."""
     return hash(str(idx) + "feature") % 10000
+
+
+def stable_seed(idx):
+    """The default: the same role as losses.py:126 (one seed in [0, 10000) per feature index) from a hash that does
+    not depend on the process, so every rank and every run of a data-parallel job picks the same channel subsets."""
+    import zlib
+    return zlib.crc32((str(idx) + "feature").encode()) % 10000
 
 
 def _stream():
@@ -74,14 +82,14 @@ def _log2_factor(big, small):
 
 
 class SelfRegLoss(nn.Module):
-    """`SelfRegLoss()` as the reference builds it; `seed_of(idx)` (default: the reference's expression) gives the
+    """`SelfRegLoss()` as the reference builds it; `seed_of(idx)` (default: `stable_seed`; `reference_seed` is the reference's expression) gives the
     seed of the channel subset LSRC takes from feature idx."""
 
     W_CE, W_DICE, W_AUX = 0.4, 0.6, 0.015                  # losses.py:72
 
     def __init__(self, seed_of=None):
         super().__init__()
-        self.seed_of = seed_of or reference_seed
+        self.seed_of = seed_of or stable_seed
         self._subsets = {}                                 # (device, idx, C, Cf, seed) -> (n, sel_f, sel_p)
 
     # ---- constants ------------------------------------------------------------------------------------------
