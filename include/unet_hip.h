@@ -263,6 +263,14 @@ int uh_adam_step(long long n, float* p, const float* g, float* m, float* v, floa
 size_t uh_bce_logits_workspace(long long n);
 int uh_bce_logits(long long n, const float* logits, const float* targets, float grad_scale, float* loss,
                   float* dlogits, void* workspace, size_t workspace_bytes, uh_stream s);
+/* The same computation, same results, for callers that cannot allocate (code under HIP graph capture, serving loops
+ * that must stay off the allocator).  It has no counterpart in the reference.  The per-workgroup partial sums live in a
+ * 4 KiB array inside the library's code object (one copy per GPU, held until the process ends) instead of a caller
+ * workspace; the call allocates and frees nothing.  n <= 2^32 elements, larger n is refused with UH_ERR_SHAPE.  The
+ * device address of the array is looked up on the first call on each device: make that call outside graph capture,
+ * with the device current.  All calls on one GPU share the array: calls that overlap on one GPU race. */
+int uh_bce_logits_noalloc(long long n, const float* logits, const float* targets, float grad_scale, float* loss,
+                          float* dlogits, uh_stream s);
 
 /* ---- self-regularisation loss (models/losses.py:6-217; trainer/training_utils.py:100-101,142-143) ------------
  * loss = 0.4*CE + 0.6*Dice + 0.015*(LSRC + LIFD) (losses.py:72).  For one-channel logits the CE term and its

@@ -79,6 +79,7 @@ SIGNATURES = {
     "uh_confusion_counts": (I, [I, L, P, P, P, P]),
     "uh_bce_logits_workspace": (Z, [L]),
     "uh_bce_logits": (I, [L, P, P, F, P, P, P, Z, P]),
+    "uh_bce_logits_noalloc": (I, [L, P, P, F, P, P, P]),
     "uh_selfreg_pool2": (I, [I, I, I, I, P, I, I, I, P, P]),
     "uh_selfreg_stat_parts": (I, [I, I, I, I]),
     "uh_selfreg_plane_stats": (I, [I, I, I, I, P, I, I, P, P]),

@@ -121,3 +121,54 @@ extern "C" int uh_bce_logits(long long n, const float* logits, const float* targ
                      (const float*)workspace, loss);
   return uh_check_launch("uh_bce_logits");
 }
+
+// ---- the same loss for callers that cannot allocate ------------------------------------------------------------
+// uh_bce_logits needs a workspace the caller allocates.  Code under HIP graph capture, or a serving loop that must
+// not touch the allocator, has nowhere to get one; for it the per-workgroup sums live in `scratch`, an array of this
+// code object (one copy per GPU, held until the process ends).  On the host the array's NAME is only a handle: the
+// device address comes from hipGetSymbolAddress, once per device with that device current, and only that pointer is
+// handed to the kernels.  Nothing has to be cleared between calls: a call writes partial[0 .. blocks) and reads exactly
+// those.  All calls on one GPU share the array, so calls that overlap in time on one GPU (two streams) race.
+#define UH_BCE_NOALLOC_PARTIALS 1024                       /* bce_blocks() never exceeds it */
+#define UH_BCE_NOALLOC_MAX_N (1ll << 32)
+#define UH_MAX_DEVICES 64
+static __device__ __align__(256) float scratch[UH_BCE_NOALLOC_PARTIALS];
+
+#include <mutex>
+static std::mutex g_scratch_mutex;
+static float* g_scratch_ptr[UH_MAX_DEVICES];               // device address of `scratch`, per device
+
+extern "C" int uh_bce_logits_noalloc(long long n, const float* logits, const float* targets, float grad_scale,
+                                     float* loss, float* dlogits, uh_stream s) {
+  UH_REQUIRE(n > 0 && logits && targets && loss, "uh_bce_logits_noalloc: n=%lld or a null pointer", n);
+  UH_REQUIRE(n <= UH_BCE_NOALLOC_MAX_N, "uh_bce_logits_noalloc: n=%lld exceeds the maximum of %lld elements", n,
+             (long long)UH_BCE_NOALLOC_MAX_N);
+  const int blocks = bce_blocks(n);
+  UH_REQUIRE(blocks <= UH_BCE_NOALLOC_PARTIALS, "uh_bce_logits_noalloc: %d partial sums exceed the scratch array of %d",
+             blocks, UH_BCE_NOALLOC_PARTIALS);
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= UH_MAX_DEVICES) {
+    uh_set_error("uh_bce_logits_noalloc: no current device (or device index above %d)", UH_MAX_DEVICES - 1);
+    return UH_ERR_HIP;
+  }
+  float* partial;
+  {
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {                             // first call on this device
+      void* ptr = nullptr;
+      const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+      if (e != hipSuccess || !ptr) {
+        uh_set_error("uh_bce_logits_noalloc: hipGetSymbolAddress(scratch) failed on device %d: %s", dev,
+                     hipGetErrorString(e));
+        return UH_ERR_HIP;
+      }
+      g_scratch_ptr[dev] = (float*)ptr;
+    }
+    partial = g_scratch_ptr[dev];
+  }
+  hipLaunchKernelGGL(bce_logits_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, n, logits, targets,
+                     (float)((double)grad_scale / (double)n), dlogits, partial);
+  hipLaunchKernelGGL(bce_logits_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, blocks, 1.0 / (double)n,
+                     (const float*)partial, loss);
+  return uh_check_launch("uh_bce_logits_noalloc");
+}
