@@ -4,13 +4,16 @@
  * the ATen calls its nn.Module / loss code dispatches, cited per entry point as
  * reference file:line.  Every function
  *   - takes plain device pointers and sizes (no framework types),
- *   - allocates nothing, keeps no global mutable state, never synchronises the device,
+ *   - allocates nothing, never synchronises the device, and keeps no state between calls except two mutex-guarded,
+ *     per-device records (which kernels have had their dynamic-LDS limit raised; the address of the scratch array of
+ *     uh_bce_logits_noalloc), so one process may drive several GPUs from several threads,
  *   - enqueues its kernels on `stream` (a hipStream_t passed as void*),
  *   - returns UH_OK or a negative uh_status; uh_last_error() gives the thread-local message.
  *
  * Activation layout ("padded-linear NHWC", bf16): a logical [B][H][W][C] tensor is stored as
  * Mp = B*(H+1)*(W+1) rows of C channels, row m = (b*(H+1)+y)*(W+1)+x; rows with y==H or x==W
- * are zero, and uh_guard_rows(W) zero rows precede row 0 and follow row Mp-1.  Pointers passed
+ * are zero, and uh_guard_rows(W) guard rows precede row 0 and follow row Mp-1 (zero on entry; kernels read them and
+ * may rewrite them with zeros).  Pointers passed
  * here address row 0.  `cstride`/`coff` select a channel window of a wider buffer (skip concat).
  */
 #ifndef UNET_HIP_H

@@ -656,3 +656,4 @@ def test_conv_dgrad_with_batchnorm_backward_sums(B, H, W, Cin, Cout):
     slack = torch.stack([(da.abs() * edge).sum((0, 2, 3)), ((da * xh).abs() * edge).sum((0, 2, 3))])
     assert ((got - want).abs() <= 2e-4 * ref + slack).all(), "fused sums against double precision"
     assert ((got - sep).abs() <= 4e-3 * ref).all(), "fused sums against the separate pass"
+

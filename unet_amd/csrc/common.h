@@ -5,8 +5,11 @@
 //   position of a grid that has ONE extra zero column and ONE extra zero row per image:
 //       Wp = W + 1, Hp = H + 1, row index m = (b*Hp + y)*Wp + x,  Mp = B*Hp*Wp rows.
 //   A position is "interior" iff y < H and x < W; every other row is all zeros.
-//   The buffer also carries zero guard rows before row 0 and after row Mp-1
-//   (uh_guard_rows(W) rows on each side), which no kernel ever writes.
+//   The buffer also carries guard rows before row 0 and after row Mp-1 (uh_guard_rows(W) rows on each side).
+//   They start as zeros.  Kernels read them (3x3 neighbours of the first and last image rows, the overhang of
+//   the last tile) and the GEMM epilogues also WRITE the rows of a ragged last M tile that lie past Mp -- up to
+//   511 rows, always with zeros (the row flags of those rows are cleared before the multiply) -- which is why the
+//   guard is at least 512 rows long.
 //   With this layout the 3x3 neighbour (dy,dx) of row m is row m + dy*Wp + dx for EVERY
 //   interior m, and whatever lies outside the image reads as zero -- so a pad-1
 //   convolution is a GEMM whose A operand is the same matrix at nine row offsets,
@@ -30,6 +33,9 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 // ---- error plumbing (host) -------------------------------------------------
 void uh_set_error(const char* fmt, ...);
 int uh_check_launch(const char* what);
+// Raises a kernel's dynamic-LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize) once per (kernel, device); the
+// attribute belongs to the device that is current when it is set.  Thread-safe.
+void uh_set_max_lds(const void* kernel, int bytes);
 
 #define UH_REQUIRE(cond, ...)                         \
   do {                                                \

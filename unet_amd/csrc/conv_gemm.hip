@@ -16,207 +16,6 @@
 
 #include "conv_gemm.h"
 
-template <int BM, int BN>
-struct Cfg {
-  static constexpr int WN = BN / 64;       // waves along N
-  static constexpr int WM = 4 / WN;        // waves along M
-  static_assert(BM == WM * 64, "each wave owns 64 rows");
-  static constexpr int A_BYTES = BM * 128;
-  static constexpr int B_BYTES = BN * 128;
-  static constexpr int STAGE = A_BYTES + B_BYTES;
-  static constexpr int LDS_BYTES = 2 * STAGE;             // the epilogue's float[WM][2][BN] reuses it
-};
-
-template <int BM, int BN, int MODE>
-__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmArgs p) {
-  using C = Cfg<BM, BN>;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / C::WN, wn = wave % C::WN;
-  const long long m0 = (long long)blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
-  const int l15 = lane & 15, g = lane >> 4;
-
-  // ---- staging addresses: one wave-instruction copies 8 rows x 128 B ----------------------
-  // LDS row r keeps source chunk c at position c ^ ((r>>1)&7); for the rows a wave stages
-  // (groups wave, wave+4, ...) that swizzle is (4*(wave&1) + lane/16) & 7.
-  const int lrow = lane >> 3;
-  const int src_chunk = (lane & 7) ^ ((4 * (wave & 1) + g) & 7);
-  const long long a_row_bytes = (long long)p.a_cstride * 2;
-  const long long b_row_bytes = (long long)p.T * p.K * 2;
-  const char* a_lane = p.A + (m0 + 8 * wave + lrow) * a_row_bytes + (long long)p.a_coff * 2 + src_chunk * 16;
-  // Weight rows are staged in permuted order: LDS row w*64 + j*16 + c holds output column w*64 + c*4 + j, so the
-  // four accumulator tiles j = 0..3 a lane holds for one row of A are four ADJACENT columns (8-byte stores).
-  const char* b_lane[BN / 32];
-#pragma unroll
-  for (int jj = 0; jj < BN / 32; ++jj) {
-    const int r = 8 * wave + lrow + 32 * jj;
-    const int col = (r & ~63) + (r & 15) * 4 + ((r >> 4) & 3);
-    b_lane[jj] = p.Wt + (long long)(n0 + col) * b_row_bytes + src_chunk * 16;
-  }
-
-  auto stage = [&](int buf, int tap, int kc) {
-    int off = 0;
-    if (p.T == 9) off = (tap / 3 - 1) * p.Wp + (tap % 3 - 1);
-    const char* as = a_lane + (long long)off * a_row_bytes + kc * 128;
-    const long long boff = ((long long)tap * p.K + kc * 64) * 2;
-    char* lds = smem + buf * C::STAGE + wave * 1024;
-#pragma unroll
-    for (int j = 0; j < BM / 32; ++j)
-      __builtin_amdgcn_global_load_lds((const UH_GLOBAL void*)(as + j * 32 * a_row_bytes),
-                                       (UH_LDS void*)(lds + j * 4096), 16, 0, 0);
-#pragma unroll
-    for (int j = 0; j < BN / 32; ++j)
-      __builtin_amdgcn_global_load_lds((const UH_GLOBAL void*)(b_lane[j] + boff),
-                                       (UH_LDS void*)(lds + C::A_BYTES + j * 4096), 16, 0, 0);
-  };
-
-  // ---- fragment read offsets --------------------------------------------------------------
-  // row = w*64 + i*16 + l15 ; chunk = ks*4 + g ; swizzle term (row>>1)&7 == l15>>1
-  const int sw = l15 >> 1;
-  const int a_rd0 = (wm * 64 + l15) * 128 + (((0 + g) ^ sw) << 4);
-  const int a_rd1 = (wm * 64 + l15) * 128 + (((4 + g) ^ sw) << 4);
-  const int b_rd0 = (wn * 64 + l15) * 128 + (((0 + g) ^ sw) << 4);
-  const int b_rd1 = (wn * 64 + l15) * 128 + (((4 + g) ^ sw) << 4);
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int niter = p.T * p.KC;
-  int tap = 0, kc = 0;
-  stage(0, 0, 0);
-  for (int it = 0; it < niter; ++it) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (++kc == p.KC) { kc = 0; ++tap; }
-    if (it + 1 < niter) stage((it + 1) & 1, tap, kc);
-    const char* As = smem + (it & 1) * C::STAGE;
-    const char* Bs = As + C::A_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 af[4], bfr[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(As + (ks ? a_rd1 : a_rd0) + i * 2048);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(Bs + (ks ? b_rd1 : b_rd0) + j * 2048);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-    }
-  }
-
-  // ---- epilogue: straight from the accumulators ------------------------------------------------------------
-  // lane (l15, g) holds rows wm*64 + i*16 + g*4 + e and the 4 adjacent columns n0 + wn*64 + l15*4 + j
-  __syncthreads();  // every wave is done reading the staging buffers
-  float* red = (float*)smem;                       // [WM][2][BN]
-  const int ncol = wn * 64 + l15 * 4;
-  const int n = n0 + ncol;
-  float cb[4] = {0.f, 0.f, 0.f, 0.f}, csc[4] = {1.f, 1.f, 1.f, 1.f};
-  int otap = 0, co = n;
-  if (MODE == UH_EPI_CONVT) {
-    otap = n / p.Cout;
-    co = n - otap * p.Cout;
-    if (p.bias && otap < 4) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) cb[j] = p.bias[co + j];
-    }
-  } else if (MODE == UH_EPI_AFFINE_RELU) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { csc[j] = p.scale[n + j]; cb[j] = p.shift[n + j]; }
-  } else if (p.bias) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) cb[j] = p.bias[n + j];
-  }
-  const long long mask_last_dword = (p.Mp - 1) >> 2;
-  const long long o_row_bytes = (long long)p.o_cstride * 2;
-  const int Hp = p.H + 1, Wp = p.W + 1;
-  const int oHp = 2 * p.H + 1, oWp = 2 * p.W + 1;
-  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const long long mrow = m0 + wm * 64 + i * 16 + g * 4;          // first of the lane's four rows (multiple of 4)
-    long long d = mrow >> 2;
-    if (d > mask_last_dword) d = mask_last_dword;
-    const uint32_t fw = *(const uint32_t*)(p.rowmask + 4 * d);
-    // transposed conv: position of row mrow in the input geometry, stepped row by row
-    int x = 0, y = 0;
-    long long b = 0;
-    if (MODE == UH_EPI_CONVT) {
-      x = (int)(mrow % Wp);
-      const long long r = mrow / Wp;
-      y = (int)(r % Hp);
-      b = r / Hp;
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const long long m = mrow + e;
-      const float f = (m < p.Mp) ? (float)((fw >> (8 * e)) & 0xffu) : 0.f;
-      float v[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float t = acc[i][j][e];
-        if (MODE == UH_EPI_AFFINE_RELU) t = fmaxf(t * csc[j] + cb[j], 0.f);
-        else t += cb[j];
-        t *= f;
-        if (MODE == UH_EPI_RAW_STATS) {
-          s1[j] += t;
-          s2[j] += t * t;
-        }
-        v[j] = t;
-      }
-      uint2 o;
-      o.x = (MODE == UH_EPI_RAW_STATS) ? pack2h(v[0], v[1]) : pack2(v[0], v[1]);
-      o.y = (MODE == UH_EPI_RAW_STATS) ? pack2h(v[2], v[3]) : pack2(v[2], v[3]);
-      if (MODE == UH_EPI_CONVT) {
-        // column n = tap*Cout + co of input position (b,y,x) goes to output position (b, 2y + tap/2, 2x + tap%2),
-        // channel co; output geometry (B, 2H, 2W); tap >= 4: zero-padded weight rows (N > 4*Cout)
-        const int Y = 2 * y + (otap >> 1), X = 2 * x + (otap & 1);
-        if (m < p.Mp && otap < 4 && Y < oHp && X < oWp) {
-          const long long om = (b * oHp + Y) * oWp + X;
-          *(uint2*)(p.out + (om * p.o_cstride + p.o_coff + co) * 2) = o;
-        }
-        if (++x == Wp) {
-          x = 0;
-          if (++y == Hp) { y = 0; ++b; }
-        }
-      } else if (m < p.Mp) {
-        *(uint2*)(p.out + m * o_row_bytes + (long long)(p.o_coff + n) * 2) = o;
-      }
-    }
-  }
-  if (MODE == UH_EPI_RAW_STATS) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      s1[j] += __shfl_xor(s1[j], 16, 64);
-      s1[j] += __shfl_xor(s1[j], 32, 64);
-      s2[j] += __shfl_xor(s2[j], 16, 64);
-      s2[j] += __shfl_xor(s2[j], 32, 64);
-    }
-    if (g == 0) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        red[(wm * 2 + 0) * BN + ncol + j] = s1[j];
-        red[(wm * 2 + 1) * BN + ncol + j] = s2[j];
-      }
-    }
-    __syncthreads();
-    if (tid < 2 * BN) {
-      const int which = tid / BN, col = tid % BN;
-      float v = 0.f;
-#pragma unroll
-      for (int w = 0; w < C::WM; ++w) v += red[(w * 2 + which) * BN + col];
-      p.stat_partial[((long long)blockIdx.x * 2 + which) * p.N + n0 + col] = v;
-    }
-  }
-}
-
 // ===================================================================================================
 // 3x3 "band" kernel: the workhorse for T = 9.
 //
@@ -665,6 +464,242 @@ __global__ __launch_bounds__(512) void conv_band_fixup_kernel(GemmArgs p, BandSc
   }
 }
 
+// ===================================================================================================
+// T = 1 "stream" kernel: plain GEMMs out[m][n] = sum_k A[m][k] * Wp[n][k] (the k2s2 transposed convolutions and their
+// input gradients, LUNeXt's 1x1 and k2s2 convolutions).  Same machinery as the band kernel -- persistent workgroups of
+// eight 64x64 waves, global_load_lds staging with the XOR swizzle on the source chunk, counted s_waitcnt, raw
+// s_barriers with waves 4-7 running one barrier behind waves 0-3, stores straight from the accumulators -- but a stage
+// is one 32-channel slice of a BM-row A tile plus the matching slice of BN weight rows, consumed in ONE phase, and the
+// ring has four stages: stage s+2 is issued while stage s is consumed into the buffer that held stage s-2, whose last
+// readers (the lagging half, one barrier late) finished their MFMAs two barriers ago.
+//   stage s+1 is retired by the vmcnt(NQ) that follows the issue of stage s+2 in iteration s (only that stage's
+//   loads are younger) and first read after the next barrier both halves pass.
+// These GEMMs are short (K = 128 ... 2048) and the largest are HBM-bound (transposed convolution at full resolution:
+// 408 MB moved for 35 GFLOP), so what matters is that the ring runs on across tile boundaries and that stores of one
+// tile overlap the loads of the next.
+template <int BM, int BN>
+struct StreamCfg {
+  static constexpr int WN = BN / 64;
+  static constexpr int WM = 8 / WN;
+  static_assert(BM == WM * 64, "each of the eight waves owns 64 rows");
+  static constexpr int AG = BM / 16;              // 1 KiB groups (16 rows x 64 B) of the A slice
+  static constexpr int BG = BN / 16;
+  static constexpr int SG = AG + BG;
+  static constexpr int NQ = (SG + 7) / 8;         // staging slots per wave
+  static constexpr int STAGE = SG * 1024;
+  static constexpr int NSTAGE = 4;
+  static constexpr int FLAG_OFF = NSTAGE * STAGE;
+  static constexpr int RED_OFF = FLAG_OFF + 8 * 256;
+  static constexpr int LDS_BYTES = RED_OFF + WM * 2 * BN * 4;
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+// Transposed convolution k2s2 (unet.py:132-164, lunext.py:161-179): column n = tap*Cout + co of input position
+// (b, y, x) goes to output position (b, 2y + tap/2, 2x + tap%2), channel co, of the (B, 2H, 2W) output geometry.
+template <int BM, int BN>
+__device__ __forceinline__ void stream_epilogue_convt(const GemmArgs& p, const f32x4 (&acc)[4][4], int mt, int nt,
+                                                      const uint32_t (&fw)[4], int wm, int wn, int l15, int g) {
+  const int n = nt * BN + wn * 64 + l15 * 4;
+  const int otap = n / p.Cout;                     // >= 4: zero-padded weight rows (N > 4*Cout)
+  const int co = n - otap * p.Cout;
+  float cb[4] = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias && otap < 4) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cb[j] = p.bias[co + j];
+  }
+  const int Hp = p.H + 1, Wp = p.W + 1;
+  const int oHp = 2 * p.H + 1, oWp = 2 * p.W + 1;
+  // position of the lane's first row, once per tile in 32-bit arithmetic (Mp < 2^31 is checked on the host), then
+  // stepped row by row: 64-bit divisions per row group cost more than the tile's MFMAs at K = 128
+  const unsigned mrow0 = (unsigned)mt * BM + wm * 64 + g * 4;
+  int x = (int)(mrow0 % (unsigned)Wp);
+  const unsigned r = mrow0 / (unsigned)Wp;
+  int y = (int)(r % (unsigned)Hp);
+  int b = (int)(r / (unsigned)Hp);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const long long m = (long long)mrow0 + i * 16 + e;
+      const float f = (float)((fw[i] >> (8 * e)) & 0xffu);
+      uint2 o;
+      o.x = pack2((acc[i][0][e] + cb[0]) * f, (acc[i][1][e] + cb[1]) * f);
+      o.y = pack2((acc[i][2][e] + cb[2]) * f, (acc[i][3][e] + cb[3]) * f);
+      const int Y = 2 * y + (otap >> 1), X = 2 * x + (otap & 1);
+      if (m < p.Mp && otap < 4 && Y < oHp && X < oWp) {
+        const long long om = ((long long)b * oHp + Y) * oWp + X;
+        *(uint2*)(p.out + (om * p.o_cstride + p.o_coff + co) * 2) = o;
+      }
+      if (++x == Wp) {
+        x = 0;
+        if (++y == Hp) { y = 0; ++b; }
+      }
+    }
+    x += 12;                                       // to the lane's next group of four rows, 16 rows on
+    while (x >= Wp) {
+      x -= Wp;
+      if (++y == Hp) { y = 0; ++b; }
+    }
+  }
+}
+
+template <int BM, int BN, int MODE>
+__global__ __launch_bounds__(512) void conv_stream_kernel(GemmArgs p, BandSched sc) {
+  using C = StreamCfg<BM, BN>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int niter = sc.niter, ntn = sc.ntn;        // niter = K/32
+  // whole units per workgroup; each XCD (workgroups b, b+8, ...) owns one contiguous range of units
+  const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+  const int u_end = min((xcd + 1) * sc.upx, sc.ntm * ntn);
+  const int u_first = xcd * sc.upx + jx;
+  const int u_step = sc.G >> 3;
+  const int total = (u_first < u_end) ? ((u_end - u_first + u_step - 1) / u_step) * niter : 0;
+  if (total <= 0) return;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / C::WN, wn = wave % C::WN;
+  const int l15 = lane & 15, g = lane >> 4;
+
+  // ---- staging: one wave instruction = 16 rows x 64 B; lane -> (row lane/4, position lane%4) ----------
+  constexpr int NQ = C::NQ;
+  const int srow = lane >> 2;
+  const int src_chunk = (lane & 3) ^ ((srow >> 1) & 2);
+  const long long a_row_bytes = (long long)p.a_cstride * 2;
+  const long long b_row_bytes = (long long)p.K * 2;
+  const char* gp[NQ];
+  bool slot_is_a[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int gi = wave + 8 * q;
+    slot_is_a[q] = gi < C::AG;
+    const int nb = gi - C::AG;
+    const int chan = (nb >> 2) * 64 + srow * 4 + (nb & 3);
+    const char* pa = p.A + (srow + (long long)gi * 16) * a_row_bytes + (long long)p.a_coff * 2 + src_chunk * 16;
+    const char* pb = p.Wt + (long long)chan * b_row_bytes + src_chunk * 16;
+    gp[q] = slot_is_a[q] ? pa : pb;
+  }
+  const bool has_last = wave + 8 * (NQ - 1) < C::SG;
+  auto issue_stage = [&](int buf, long long offA, long long offB) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      if (q == NQ - 1 && !has_last) break;
+      const long long off = slot_is_a[q] ? offA : offB;
+      __builtin_amdgcn_global_load_lds((const UH_GLOBAL void*)(gp[q] + off),
+                                       (UH_LDS void*)(smem + buf * C::STAGE + (wave + 8 * q) * 1024), 16, 0, 0);
+    }
+  };
+  const long long mask_last_dword = (p.Mp - 1) >> 2;
+  auto issue_flags = [&](int mt) {
+    long long d = (((long long)mt * BM + wm * 64) >> 2) + l15;
+    if (d > mask_last_dword) d = mask_last_dword;
+    __builtin_amdgcn_global_load_lds((const UH_GLOBAL void*)(p.rowmask + 4 * d),
+                                     (UH_LDS void*)(smem + C::FLAG_OFF + wave * 256), 4, 0, 0);
+  };
+
+  // ---- fragment read offsets (bytes inside a stage) -----------------------------------------------------
+  const int a_off = (wm * 64 + l15) * 64 + ((g ^ ((l15 >> 1) & 2)) << 4);
+  const int b_off = C::AG * 1024 + (wn * 64 + l15) * 64 + ((g ^ ((l15 >> 1) & 2)) << 4);
+  float* red = (float*)(smem + C::RED_OFF);
+
+  long long offA, offB;
+  int u_n = u_first, kc_n = 0;
+  auto stage_offsets = [&]() {
+    const int mt_n = u_n / ntn, nt_n = u_n - mt_n * ntn;
+    offA = (long long)mt_n * BM * a_row_bytes + kc_n * 64;
+    offB = (long long)nt_n * BN * b_row_bytes + kc_n * 64;
+  };
+  auto advance = [&]() {
+    if (++kc_n == niter) {
+      kc_n = 0;
+      u_n += u_step;
+    }
+    stage_offsets();
+  };
+  stage_offsets();
+  issue_stage(0, offA, offB);
+  if (total > 1) {
+    advance();
+    issue_stage(1, offA, offB);
+    if (has_last) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ - 1) : "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  if (wave >= 4) __builtin_amdgcn_s_barrier();  // the stagger
+
+  int buf = 0, s = 0;
+  int pend_mt = -1, pend_nt = 0;
+  int u = u_first;
+  bf16x8 af[4], bfr[4];
+  while (s < total) {
+    const int mt = u / ntn, nt = u - mt * ntn;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[ii][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int c = 0; c < niter; ++c, ++s) {
+      const char* S = smem + buf * C::STAGE;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(S + b_off + j * 1024);
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii) af[ii] = *(const bf16x8*)(S + a_off + ii * 1024);
+      if (c == 0) issue_flags(mt);
+      if (MODE == UH_EPI_RAW_STATS && c == 1 && pend_mt >= 0) {
+        band_flush_stats<BM, BN>(p, red, pend_mt, pend_nt, tid);
+        pend_mt = -1;
+      }
+      if (s + 2 < total) {
+        advance();
+        issue_stage((buf + 2) & 3, offA, offB);
+        if (has_last) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ - 1) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ii], bfr[j], acc[ii][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      buf = (buf + 1) & 3;
+    }
+
+    uint32_t fw[4];
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) fw[ii] = *(const uint32_t*)(smem + C::FLAG_OFF + wave * 256 + (ii * 4 + g) * 4);
+    if constexpr (MODE == UH_EPI_CONVT) {
+      if ((long long)(mt + 1) * BM > p.Mp) {      // rows past the end of the last tile carry no valid flag
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if ((long long)mt * BM + wm * 64 + ii * 16 + g * 4 + e >= p.Mp) fw[ii] &= ~(0xffu << (8 * e));
+      }
+      stream_epilogue_convt<BM, BN>(p, acc, mt, nt, fw, wm, wn, l15, g);
+    } else {
+      band_epilogue<BM, BN, MODE>(p, acc, mt, nt, fw, wm, wn, l15, g, red);
+      if (MODE == UH_EPI_RAW_STATS) { pend_mt = mt; pend_nt = nt; }
+    }
+    u += u_step;
+  }
+  if (wave < 4) __builtin_amdgcn_s_barrier();   // match the second half's extra barrier
+  if (MODE == UH_EPI_RAW_STATS && pend_mt >= 0) {
+    __syncthreads();
+    band_flush_stats<BM, BN>(p, red, pend_mt, pend_nt, tid);
+  }
+}
+
 template <int BM, int BN>
 static size_t band_workspace_bytes(long long Mp, int N, int K) {
   const long long units = ((Mp + BM - 1) / BM) * (N / BN);
@@ -674,11 +709,7 @@ static size_t band_workspace_bytes(long long Mp, int N, int K) {
 template <int BM, int BN, int MODE>
 static void launch_band_mode(const GemmArgs& p, const BandSched& sc, hipStream_t st) {
   using C = BandCfg<BM, BN>;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)conv_band_kernel<BM, BN, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-    attr = true;
-  }
+  uh_set_max_lds((const void*)conv_band_kernel<BM, BN, MODE>, C::LDS_BYTES);
   hipLaunchKernelGGL((conv_band_kernel<BM, BN, MODE>), dim3(sc.G), dim3(512), C::LDS_BYTES, st, p, sc);
   if (!sc.aligned)
     hipLaunchKernelGGL((conv_band_fixup_kernel<BM, BN, MODE>), dim3(sc.G - 1), dim3(512), 0, st, p, sc);
@@ -710,24 +741,28 @@ static void launch_band(const GemmArgs& p, void* ws, size_t ws_bytes, hipStream_
 }
 
 template <int BM, int BN, int MODE>
-static void launch_tile_mode(const GemmArgs& p, hipStream_t st) {
-  using C = Cfg<BM, BN>;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)conv_gemm_kernel<BM, BN, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-    attr = true;
-  }
-  dim3 grid((unsigned)((p.Mp + BM - 1) / BM), p.N / BN);
-  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, MODE>), grid, dim3(256), C::LDS_BYTES, st, p);
+static void launch_stream_mode(const GemmArgs& p, const BandSched& sc, hipStream_t st) {
+  using C = StreamCfg<BM, BN>;
+  uh_set_max_lds((const void*)conv_stream_kernel<BM, BN, MODE>, C::LDS_BYTES);
+  hipLaunchKernelGGL((conv_stream_kernel<BM, BN, MODE>), dim3(sc.G), dim3(512), C::LDS_BYTES, st, p, sc);
 }
 
 template <int BM, int BN>
-static void launch_tile(const GemmArgs& p, hipStream_t st) {
+static void launch_stream(const GemmArgs& p, hipStream_t st) {
+  BandSched sc;
+  sc.ntm = (int)((p.Mp + BM - 1) / BM);
+  sc.ntn = p.N / BN;
+  sc.niter = p.K / 32;
+  const long long units = (long long)sc.ntm * sc.ntn;
+  sc.G = band_workgroups(units, sc.niter);
+  sc.ws = nullptr;
+  sc.upx = (int)((units + 7) / 8);
+  sc.aligned = 1;
   switch (p.mode) {
-    case UH_EPI_RAW_STATS: launch_tile_mode<BM, BN, UH_EPI_RAW_STATS>(p, st); break;
-    case UH_EPI_AFFINE_RELU: launch_tile_mode<BM, BN, UH_EPI_AFFINE_RELU>(p, st); break;
-    case UH_EPI_MASKED: launch_tile_mode<BM, BN, UH_EPI_MASKED>(p, st); break;
-    default: launch_tile_mode<BM, BN, UH_EPI_CONVT>(p, st); break;
+    case UH_EPI_RAW_STATS: launch_stream_mode<BM, BN, UH_EPI_RAW_STATS>(p, sc, st); break;
+    case UH_EPI_AFFINE_RELU: launch_stream_mode<BM, BN, UH_EPI_AFFINE_RELU>(p, sc, st); break;
+    case UH_EPI_MASKED: launch_stream_mode<BM, BN, UH_EPI_MASKED>(p, sc, st); break;
+    default: launch_stream_mode<BM, BN, UH_EPI_CONVT>(p, sc, st); break;
   }
 }
 
@@ -763,6 +798,8 @@ extern "C" int uh_conv_gemm_ws(int B, int H, int W, const void* a, int a_cstride
   UH_REQUIRE(K > 0 && K % 64 == 0, "conv_gemm: K=%d must be a positive multiple of 64", K);
   UH_REQUIRE(N > 0 && N % 64 == 0, "conv_gemm: N=%d must be a positive multiple of 64", N);
   UH_REQUIRE(T == 1 || T == 9, "conv_gemm: T=%d must be 1 or 9", T);
+  UH_REQUIRE(uh_mp(B, H, W) < (1ll << 31) - 1024, "conv_gemm: %lld rows exceed the 32-bit row arithmetic of the kernels",
+             uh_mp(B, H, W));
   UH_REQUIRE(mode >= UH_EPI_RAW_STATS && mode <= UH_EPI_CONVT, "conv_gemm: bad mode %d", mode);
   UH_REQUIRE(a && w_packed && out && rowmask, "conv_gemm: null pointer");
   UH_REQUIRE(a_cstride >= a_coff + K && a_cstride % 8 == 0 && a_coff % 8 == 0,
@@ -813,9 +850,9 @@ extern "C" int uh_conv_gemm_ws(int B, int H, int W, const void* a, int a_cstride
     else
       launch_band<256, 128>(p, workspace, workspace_bytes, st);
   } else if (use_wide_m(N)) {
-    launch_tile<256, 64>(p, st);
+    launch_stream<512, 64>(p, st);
   } else {
-    launch_tile<128, 128>(p, st);
+    launch_stream<256, 128>(p, st);
   }
   return uh_check_launch("conv_gemm");
 }

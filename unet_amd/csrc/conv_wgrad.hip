@@ -154,9 +154,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs p) {
       }
 }
 
-static int wgrad_splits(long long Mp, int N, int K) {
+static int wgrad_splits(long long Mp, int N, int K, int T) {
   const long long stages = (Mp + 127) / 128;
   const long long tiles = (long long)(N / 64) * (K / 64);
+  (void)T;
   long long want = (512 + tiles - 1) / tiles;        // aim at ~512 workgroups (two per CU): every split costs a slab
   if (want > stages) want = stages;
   if (want < 1) want = 1;
@@ -165,12 +166,11 @@ static int wgrad_splits(long long Mp, int N, int K) {
 }
 
 extern "C" int uh_conv_wgrad_splits(int B, int H, int W, int N, int K, int T) {
-  (void)T;
-  return wgrad_splits(uh_mp(B, H, W), N, K);
+  return wgrad_splits(uh_mp(B, H, W), N, K, T);
 }
 
 extern "C" size_t uh_conv_wgrad_workspace(int B, int H, int W, int N, int K, int T) {
-  return (size_t)wgrad_splits(uh_mp(B, H, W), N, K) * N * T * K * sizeof(float);
+  return (size_t)wgrad_splits(uh_mp(B, H, W), N, K, T) * N * T * K * sizeof(float);
 }
 
 extern "C" int uh_conv_wgrad(int B, int H, int W, const void* dy, int dy_cstride, int dy_coff, int N,
@@ -187,7 +187,7 @@ extern "C" int uh_conv_wgrad(int B, int H, int W, const void* dy, int dy_cstride
   p.A = (const char*)a;
   p.partial = partial;
   p.Mp = uh_mp(B, H, W);
-  const int S = wgrad_splits(p.Mp, N, K);
+  const int S = wgrad_splits(p.Mp, N, K, T);
   const long long stages = (p.Mp + 127) / 128;
   p.rows_per_split = ((stages + S - 1) / S) * 128;
   p.dy_cstride = dy_cstride;
@@ -203,11 +203,7 @@ extern "C" int uh_conv_wgrad(int B, int H, int W, const void* dy, int dy_cstride
   if (p.remap) grid = dim3((unsigned)(8 * ((S + 7) / 8) * (N / 64) * (K / 64)), 1, 1);
   hipStream_t st = (hipStream_t)s;
   if (T == 9) {
-    static bool attr = false;
-    if (!attr) {
-      (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, WCfg<9>::LDS_BYTES);
-      attr = true;
-    }
+    uh_set_max_lds((const void*)conv_wgrad_kernel<9>, WCfg<9>::LDS_BYTES);
     hipLaunchKernelGGL((conv_wgrad_kernel<9>), grid, dim3(256), WCfg<9>::LDS_BYTES, st, p);
   } else {
     hipLaunchKernelGGL((conv_wgrad_kernel<1>), grid, dim3(256), WCfg<1>::LDS_BYTES, st, p);

@@ -2,6 +2,9 @@
 #include <stdarg.h>
 #include <math.h>
 #include <stdio.h>
+#include <mutex>
+#include <set>
+#include <utility>
 #include "common.h"
 
 static thread_local char g_err[512] = "";
@@ -20,6 +23,16 @@ int uh_check_launch(const char* what) {
     return UH_ERR_HIP;
   }
   return UH_OK;
+}
+
+void uh_set_max_lds(const void* kernel, int bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<const void*, int>> done;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(mu);
+  if (done.insert(std::make_pair(kernel, dev)).second)
+    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
 extern "C" const char* uh_last_error(void) { return g_err; }
