@@ -657,3 +657,80 @@ def test_conv_dgrad_with_batchnorm_backward_sums(B, H, W, Cin, Cout):
     assert ((got - want).abs() <= 2e-4 * ref + slack).all(), "fused sums against double precision"
     assert ((got - sep).abs() <= 4e-3 * ref).all(), "fused sums against the separate pass"
 
+
+# ---- AttentionGate kernels (lunext.py:76-122) ---------------------------------------------------------------------
+@pytest.mark.parametrize("B,H,W,C", [(2, 8, 8, 64), (1, 6, 10, 128), (2, 4, 4, 256)])
+def test_gate_pointwise_forward_backward(B, H, W, C):
+    """uh_gate_fwd / uh_gate_bwd: out = sigmoid(z1) * tanh(z2) + sigmoid(z3) * x on z = [z1 | z2 | z3]"""
+    g = torch.Generator().manual_seed(31)
+    z = bf(torch.randn(B, 3 * C, H, W, generator=g))
+    x = bf(torch.randn(B, C, H, W, generator=g))
+    dout = bf(torch.randn(B, C, H, W, generator=g))
+    za, xa, da = act_from(z), act_from(x), act_from(dout)
+    out = new_act(B, H, W, C, DEV)
+    call("uh_gate_fwd", za.Mp, C, za.ptr, za.cstride, 0, xa.ptr, xa.cstride, xa.coff, out.ptr, out.cstride, out.coff, S())
+    zt, xt = z.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    z1, z2, z3 = zt[:, :C], zt[:, C:2 * C], zt[:, 2 * C:]
+    want = torch.sigmoid(z1) * torch.tanh(z2) + torch.sigmoid(z3) * xt
+    want.backward(dout)
+    torch.cuda.synchronize()
+    close(out.to_nchw(), want, 1e-2, "gate forward")
+    pads_are_zero(out)
+    dz, dxd = new_act(B, H, W, 3 * C, DEV), new_act(B, H, W, C, DEV)
+    call("uh_gate_bwd", za.Mp, C, da.ptr, da.cstride, da.coff, za.ptr, za.cstride, 0, xa.ptr, xa.cstride, xa.coff,
+         rowmask(B, H, W).data_ptr(), dz.ptr, dz.cstride, 0, dxd.ptr, dxd.cstride, dxd.coff, S())
+    torch.cuda.synchronize()
+    close(dz.to_nchw(), zt.grad, 1e-2, "gate backward: dz")
+    close(dxd.to_nchw(), xt.grad, 1e-2, "gate backward: the direct path to x")
+    pads_are_zero(dz)
+    pads_are_zero(dxd)
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 16, 16, 3), (1, 8, 12, 2), (3, 4, 4, 8)])
+def test_gate8_forward_backward(B, H, W, C):
+    """uh_gate8_fwd / uh_gate8_bwd: the whole gate of the 8-channel level in one kernel (lunext.py:100-117):
+    out = sigmoid(W1 g + b1) * tanh(W2 g + b2) + sigmoid(W3 (g + x) + b3) * x, and its gradients"""
+    gen = torch.Generator().manual_seed(37)
+    gt = bf(torch.randn(B, C, H, W, generator=gen)).requires_grad_(True)
+    xt = bf(torch.randn(B, C, H, W, generator=gen)).requires_grad_(True)
+    dout = bf(torch.randn(B, C, H, W, generator=gen))
+    Ws = [torch.randn(C, C, generator=gen).requires_grad_(True) for _ in range(3)]
+    bs = [torch.randn(C, generator=gen).requires_grad_(True) for _ in range(3)]
+
+    def lin(Wm, b, t):
+        return torch.einsum("oc,bchw->bohw", Wm, t) + b.view(1, -1, 1, 1)
+    want = (torch.sigmoid(lin(Ws[0], bs[0], gt)) * torch.tanh(lin(Ws[1], bs[1], gt))
+            + torch.sigmoid(lin(Ws[2], bs[2], gt + xt)) * xt)
+    want.backward(dout)
+    wts = torch.zeros(216)
+    for j in range(3):
+        wts[64 * j:64 * j + 64].view(8, 8)[:C, :C] = Ws[j].detach()
+        wts[192 + 8 * j:192 + 8 * j + C] = bs[j].detach()
+    wts = wts.to(DEV)
+
+    def act8(t):
+        a = new_act(B, H, W, 8, DEV)
+        full = torch.zeros(B, 8, H, W)
+        full[:, :C] = t.detach()
+        a.fill_from_nchw(full.to(DEV))
+        return a
+    ga, xa, da = act8(gt), act8(xt), act8(dout)
+    out = new_act(B, H, W, 8, DEV)
+    mask = rowmask(B, H, W).data_ptr()
+    call("uh_gate8_fwd", ga.Mp, C, ga.ptr, ga.cstride, ga.coff, xa.ptr, xa.cstride, xa.coff, wts.data_ptr(), mask,
+         out.ptr, out.cstride, out.coff, S())
+    torch.cuda.synchronize()
+    close(out.to_nchw()[:, :C], want, 1e-2, "gate8 forward")
+    pads_are_zero(out)
+    dg, dx = new_act(B, H, W, 8, DEV), new_act(B, H, W, 8, DEV)
+    parts = lib.uh_gate8_parts(ga.Mp)
+    part = torch.zeros(parts * 216, device=DEV)
+    call("uh_gate8_bwd", ga.Mp, C, da.ptr, da.cstride, da.coff, ga.ptr, ga.cstride, ga.coff, xa.ptr, xa.cstride, xa.coff,
+         wts.data_ptr(), dg.ptr, dg.cstride, dg.coff, dx.ptr, dx.cstride, dx.coff, part.data_ptr(), S())
+    torch.cuda.synchronize()
+    close(dg.to_nchw()[:, :C], gt.grad, 1e-2, "gate8 backward: dg")
+    close(dx.to_nchw()[:, :C], xt.grad, 1e-2, "gate8 backward: dx")
+    gw = part.view(parts, 216).double().sum(0).float().cpu()
+    for j in range(3):
+        close(gw[64 * j:64 * j + 64].view(8, 8)[:C, :C], Ws[j].grad, 2e-3, f"gate8 backward: dW{j + 1}")
+        close(gw[192 + 8 * j:192 + 8 * j + C], bs[j].grad, 2e-3, f"gate8 backward: db{j + 1}")
