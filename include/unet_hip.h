@@ -315,6 +315,17 @@ int uh_selfreg_loss_fwd(int B, long long n, const float* logits, const float* ta
 int uh_selfreg_loss_bwd(int B, long long n, const float* logits, const float* targets, const float* coef,
                         const float* gout, float w_dice, float* dlogits, uh_stream s);
 
+/* ---- input pipeline: FloatTensor(images).permute(0, 3, 1, 2) + TensorDataset + shuffling DataLoader
+ * (trainer/training_utils.py:52-84) as one gather per batch from a data set that stays on the device in the loaders'
+ * own layout.  data: [n_items][H][W][C], bytes (every value of the loader's fp32 array is lut[byte]; lut[k] =
+ * fp32(k)/fp32(255) for arrays made by data_helpers/utils.py:58-62) or fp32; idx: b int64 item numbers on the
+ * device (an index outside [0, n_items) leaves its slice of out untouched); out: [b][C][H][W] fp32, exactly the
+ * values FloatTensor(images).permute(0, 3, 1, 2)[idx] holds. */
+int uh_gather_batch_u8(int b, int n_items, int H, int W, int C, const uint8_t* data, const long long* idx,
+                       const float* lut, float* out, uh_stream s);
+int uh_gather_batch_f32(int b, int n_items, int H, int W, int C, const float* data, const long long* idx,
+                        float* out, uh_stream s);
+
 /* ---- evaluation: binarised predictions and confusion counts, fp32 logits and masks [planes][n] ---------
  * pred = sigmoid(logit) > 0.5 evaluated in fp32 (trainer/k_fold.py:289-290; test_helper/utils.py:130-131), so
  * logit 0 and NaN are background; counted against mask == 1 / mask == 0 exactly (k_fold.py:371-380: other

@@ -82,3 +82,26 @@ def test_metric_formulas_match_reference_fixture(golden_dir):
         per = trainer.sample_metrics_from_counts(counts)
         for i, k in enumerate(sample_keys):
             np.testing.assert_array_equal(per[k], fx[c + ".sample"][:, i], err_msg=f"{c}.{k}")
+
+
+def test_byte_storage_is_chosen_only_when_it_is_exact():
+    """the loaders' arrays (uint8 / 255 in fp32, data_helpers/utils.py:58-62; 0/1 masks) are stored as bytes, anything
+    else stays fp32: the table lookup must give back every value bit for bit"""
+    import numpy as np
+    from unet_amd.data import quantize_exact, _LUT
+    rng = np.random.default_rng(0)
+    k = rng.integers(0, 256, size=(3, 8, 6, 3), dtype=np.uint8)
+    img = np.array(k, dtype=np.float32) / 255.0                       # the loaders' expression
+    q, ok = quantize_exact(img, chunk=2)
+    assert ok and q.dtype == np.uint8 and np.array_equal(q, k)
+    assert np.array_equal(_LUT[q].view(np.uint32), img.view(np.uint32))
+    mask = (rng.random((3, 8, 6, 1)) > 0.5).astype(np.float32)
+    q, ok = quantize_exact(mask)
+    assert ok and set(np.unique(q)) <= {0, 255}
+    assert quantize_exact(rng.random((2, 4, 4, 3), dtype=np.float32))[1] is False      # arbitrary floats
+    bad = img.copy(); bad[1, 2, 3, 0] = np.nextafter(bad[1, 2, 3, 0], np.float32(2))   # one ulp off
+    assert quantize_exact(bad)[1] is False
+    for v in (np.nan, -0.25, 1.5):
+        bad = img.copy(); bad[0, 0, 0, 0] = v
+        assert quantize_exact(bad)[1] is False
+    assert quantize_exact(k)[1] is True                                # bytes are taken as they are

@@ -7,6 +7,7 @@ Public surface (same names and call conventions as the reference):
     train_model                       trainer/training_utils.py
     evaluate_model, calculate_metrics trainer/k_fold.py
     save_results                      test_helper/utils.py
+    DeviceDataset                     the device-resident counterpart of training_utils.py:52-84 (TensorDataset + DataLoader)
 Everything executes in hand-written HIP kernels behind the C ABI of include/unet_hip.h.
 """
 from ._lib import lib, LIB_PATH, HipKernelError          # noqa: F401  (fails loudly if the .so is missing)
@@ -15,6 +16,7 @@ from .lunext import LUNeXt                               # noqa: F401
 from .model_utils import create_unet, create_lunext, save_model   # noqa: F401
 from .cl_dice import soft_dice_cldice, soft_cldice, soft_dice, SoftSkeletonize   # noqa: F401
 from .self_reg import SelfRegLoss                         # noqa: F401
+from .data import DeviceDataset                         # noqa: F401
 from .trainer import train_model, evaluate_model, calculate_metrics, save_results   # noqa: F401
 
-__all__ = ["train_model", "evaluate_model", "calculate_metrics", "save_results", "UNet", "LUNeXt", "soft_dice_cldice", "soft_cldice", "soft_dice", "SoftSkeletonize", "create_unet", "create_lunext", "save_model", "lib", "LIB_PATH", "HipKernelError"]
+__all__ = ["train_model", "evaluate_model", "calculate_metrics", "save_results", "UNet", "LUNeXt", "soft_dice_cldice", "soft_cldice", "soft_dice", "SoftSkeletonize", "create_unet", "create_lunext", "save_model", "DeviceDataset", "lib", "LIB_PATH", "HipKernelError"]

@@ -76,6 +76,8 @@ SIGNATURES = {
     "uh_gate8_bwd": (I, [L, I, P, I, I, P, I, I, P, I, I, P, P, I, I, P, I, I, P, P]),
     "uh_nchw_to_c8": (I, [I, I, I, I, P, P, I, I, P]),
     "uh_adam_step": (I, [L, P, P, P, P, F, F, F, F, F, I, P]),
+    "uh_gather_batch_u8": (I, [I, I, I, I, I, P, P, P, P, P]),
+    "uh_gather_batch_f32": (I, [I, I, I, I, I, P, P, P, P]),
     "uh_confusion_counts": (I, [I, L, P, P, P, P]),
     "uh_bce_logits_workspace": (Z, [L]),
     "uh_bce_logits": (I, [L, P, P, F, P, P, P, Z, P]),

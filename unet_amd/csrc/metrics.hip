@@ -122,6 +122,98 @@ extern "C" int uh_bce_logits(long long n, const float* logits, const float* targ
   return uh_check_launch("uh_bce_logits");
 }
 
+// ---- input pipeline (trainer/training_utils.py:52-84) -------------------------------------------------------------
+// The reference turns the whole data set into fp32 NCHW on the host (FloatTensor(images).permute(0, 3, 1, 2)) and
+// lets three DataLoader workers collate shuffled batches of it.  Here the data set stays on the device as it was
+// loaded -- NHWC, one byte per value when every value is k/255 for an integer k (what the loaders produce from 8-bit
+// files: data_helpers/utils.py:58-62), fp32 NHWC otherwise -- and one launch gathers a batch by index, converts and
+// transposes it to the fp32 NCHW tensor the model takes.  HBM-bound: C bytes (or 4C) read, 4C bytes written per pixel.
+// out[i][c][p] = lut[data[idx[i]][p][c]]  (u8)   |   data[idx[i]][p][c]  (f32);   p = y*W + x
+template <int C, bool U8>
+__global__ __launch_bounds__(256) void gather_batch_kernel(int n_items, long long hw, const void* __restrict__ data,
+                                                           const long long* __restrict__ idx,
+                                                           const float* __restrict__ lut, float* __restrict__ out) {
+  // one thread: four consecutive pixels of one image (hw % 4 == 0): 4*C input values -> C float4 stores
+  const long long q = hw >> 2;
+  const long long total = (long long)gridDim.y * q;
+  (void)total;
+  const int i = blockIdx.y;
+  const long long item = idx[i];
+  if (item < 0 || item >= n_items) return;                  // the host checks its own indices; never read outside
+  for (long long p4 = (long long)blockIdx.x * 256 + threadIdx.x; p4 < q; p4 += (long long)gridDim.x * 256) {
+    float v[4 * C];
+    if (U8) {
+      const uint32_t* src = (const uint32_t*)((const uint8_t*)data + (item * hw + p4 * 4) * C);
+      uint32_t w[C];
+#pragma unroll
+      for (int k = 0; k < C; ++k) w[k] = src[k];
+#pragma unroll
+      for (int k = 0; k < 4 * C; ++k) v[k] = lut[(w[k >> 2] >> (8 * (k & 3))) & 0xffu];
+    } else {
+      const float4* src = (const float4*)((const float*)data + (item * hw + p4 * 4) * C);
+#pragma unroll
+      for (int k = 0; k < C; ++k) {
+        const float4 t = src[k];
+        v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+      *(float4*)(out + ((long long)i * C + c) * hw + p4 * 4) = float4{v[c], v[C + c], v[2 * C + c], v[3 * C + c]};
+  }
+}
+
+// any channel count / plane size: one thread per output value
+template <bool U8>
+__global__ __launch_bounds__(256) void gather_batch_generic_kernel(int n_items, long long hw, int C,
+                                                                   const void* __restrict__ data,
+                                                                   const long long* __restrict__ idx,
+                                                                   const float* __restrict__ lut,
+                                                                   float* __restrict__ out) {
+  const int i = blockIdx.y;
+  const long long item = idx[i];
+  if (item < 0 || item >= n_items) return;
+  const long long per = hw * C;
+  for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < per; o += (long long)gridDim.x * 256) {
+    const long long c = o / hw, p = o - c * hw;
+    const long long src = (item * hw + p) * C + c;
+    out[(long long)i * per + o] = U8 ? lut[((const uint8_t*)data)[src]] : ((const float*)data)[src];
+  }
+}
+
+template <bool U8>
+static int gather_batch_launch(int b, int n_items, int H, int W, int C, const void* data, const long long* idx,
+                               const float* lut, float* out, uh_stream s) {
+  UH_REQUIRE(b > 0 && b <= 65535 && n_items > 0 && H > 0 && W > 0 && C > 0, "gather_batch: bad sizes b=%d n=%d %dx%dx%d",
+             b, n_items, H, W, C);
+  UH_REQUIRE(data && idx && out && (!U8 || lut), "gather_batch: null pointer");
+  const long long hw = (long long)H * W;
+  const bool fast = hw % 4 == 0 && C <= 4 && ((uintptr_t)data & 15) == 0 && ((uintptr_t)out & 15) == 0;
+  long long work = fast ? hw / 4 : hw * C;
+  long long bx = (work + 255) / 256;
+  if (bx > 4096) bx = 4096;
+  const dim3 grid((unsigned)bx, (unsigned)b);
+  hipStream_t st = (hipStream_t)s;
+#define UH_GATHER(CC) hipLaunchKernelGGL((gather_batch_kernel<CC, U8>), grid, dim3(256), 0, st, n_items, hw, data, idx, lut, out)
+  if (fast && C == 1) UH_GATHER(1);
+  else if (fast && C == 2) UH_GATHER(2);
+  else if (fast && C == 3) UH_GATHER(3);
+  else if (fast && C == 4) UH_GATHER(4);
+  else
+    hipLaunchKernelGGL((gather_batch_generic_kernel<U8>), grid, dim3(256), 0, st, n_items, hw, C, data, idx, lut, out);
+#undef UH_GATHER
+  return uh_check_launch("gather_batch");
+}
+
+extern "C" int uh_gather_batch_u8(int b, int n_items, int H, int W, int C, const uint8_t* data, const long long* idx,
+                                  const float* lut, float* out, uh_stream s) {
+  return gather_batch_launch<true>(b, n_items, H, W, C, data, idx, lut, out, s);
+}
+extern "C" int uh_gather_batch_f32(int b, int n_items, int H, int W, int C, const float* data, const long long* idx,
+                                   float* out, uh_stream s) {
+  return gather_batch_launch<false>(b, n_items, H, W, C, data, idx, nullptr, out, s);
+}
+
 // ---- the same loss for callers that cannot allocate ------------------------------------------------------------
 // uh_bce_logits needs a workspace the caller allocates.  Code under HIP graph capture, or a serving loop that must
 // not touch the allocator, has nowhere to get one; for it the per-workgroup sums live in `scratch`, an array of this

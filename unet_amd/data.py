@@ -1,0 +1,113 @@
+"""The input pipeline of trainer/training_utils.py:52-84 on the device.
+
+The reference converts the whole data set to fp32 NCHW on the host (`FloatTensor(images).permute(0, 3, 1, 2)`), wraps
+it in a TensorDataset and lets a shuffling DataLoader with three worker processes collate batches (786 KB per
+3x256x256 image through pinned memory).  At a few thousand images per second that starves the GPU.  Here the data set is
+uploaded once, in the layout the loaders produce (NHWC), as BYTES whenever that loses nothing: the loaders make their
+fp32 arrays as `np.array(img, dtype=float32) / 255.0` from 8-bit files (data_helpers/utils.py:58-62) and masks as 0/1,
+so every value is fp32(k)/fp32(255) for an integer k, and a 256-entry table reproduces it bit for bit.  Arrays that are
+not of that form stay fp32.  A batch is one kernel launch (`uh_gather_batch_*`): gather by index, convert, transpose to
+the fp32 NCHW tensor the model takes -- exactly the values `FloatTensor(images).permute(0, 3, 1, 2)[idx]` holds.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+_LUT = (np.arange(256, dtype=np.float32) / np.float32(255.0)).astype(np.float32)     # the loaders' own expression
+
+
+def quantize_exact(array, chunk=64):
+    """array [N,H,W,C] (or [N,H,W]) fp32/uint8 -> (uint8 array, True) if every value is _LUT[k] for some byte k
+    (uint8 input is taken as k itself, i.e. as the loaders' array before their /255), else (None, False).
+    Works through the array `chunk` items at a time, so the host never holds a second fp32 copy."""
+    a = np.asarray(array)
+    if a.dtype == np.uint8:
+        return a, True
+    if a.dtype != np.float32:
+        return None, False
+    out = np.empty(a.shape, dtype=np.uint8)
+    for i in range(0, len(a), chunk):
+        part = a[i:i + chunk]
+        with np.errstate(invalid="ignore"):
+            k = np.rint(part * np.float32(255.0))
+        if not np.all((k >= 0) & (k <= 255)):               # also false for NaN
+            return None, False
+        k = k.astype(np.uint8)
+        if not np.array_equal(_LUT[k], part):
+            return None, False
+        out[i:i + chunk] = k
+    return out, True
+
+
+class DeviceTensorSet:
+    """One array of the data set ([N,H,W,C] as the loaders give it) resident on the device, bytes when exact."""
+
+    def __init__(self, array, device):
+        a = np.asarray(array)
+        if a.ndim == 3:
+            a = a[..., None]
+        if a.ndim != 4:
+            raise ValueError(f"expected [N,H,W,C] or [N,H,W], got shape {a.shape}")
+        self.n, self.H, self.W, self.C = (int(v) for v in a.shape)
+        self.device = torch.device(device)
+        q, exact = quantize_exact(a)
+        self.is_bytes = exact
+        if exact:
+            self.data = torch.from_numpy(np.ascontiguousarray(q)).to(self.device)
+            self.lut = torch.from_numpy(_LUT).to(self.device)
+        else:
+            self.data = torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).to(self.device)
+            self.lut = None
+
+    def __len__(self):
+        return self.n
+
+    def gather(self, idx):
+        """idx: int64 tensor on the device -> [len(idx), C, H, W] fp32."""
+        if idx.dtype != torch.int64 or idx.device != self.device:
+            idx = idx.to(self.device, torch.int64)
+        idx = idx.contiguous()
+        b = idx.numel()
+        out = torch.empty(b, self.C, self.H, self.W, dtype=torch.float32, device=self.device)
+        if b == 0:
+            return out
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        for lo in range(0, b, 65535):                       # the launch takes one grid row per item
+            n = min(65535, b - lo)
+            o = out[lo:lo + n]
+            if self.is_bytes:
+                _lib.call("uh_gather_batch_u8", n, self.n, self.H, self.W, self.C, self.data.data_ptr(),
+                          idx.data_ptr() + 8 * lo, self.lut.data_ptr(), o.data_ptr(), s)
+            else:
+                _lib.call("uh_gather_batch_f32", n, self.n, self.H, self.W, self.C, self.data.data_ptr(),
+                          idx.data_ptr() + 8 * lo, o.data_ptr(), s)
+        return out
+
+
+class DeviceDataset:
+    """(images, masks) of trainer/training_utils.py:47-55 on the device; `batch(idx)` replaces one DataLoader step."""
+
+    def __init__(self, images, masks, device):
+        self.images = DeviceTensorSet(images, device)
+        self.masks = DeviceTensorSet(masks, device)
+        if len(self.images) != len(self.masks):
+            raise ValueError(f"{len(self.images)} images but {len(self.masks)} masks")
+        self.device = self.images.device
+
+    def __len__(self):
+        return len(self.images)
+
+    def batch(self, idx):
+        if not torch.is_tensor(idx):
+            idx = torch.as_tensor(idx, dtype=torch.int64)
+        n = len(self)
+        # host indices are checked here; for indices already on the device a check would cost a synchronisation, and
+        # the kernel leaves the slice of an out-of-range index untouched rather than reading outside the data set
+        if idx.device.type == "cpu" and idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= n):
+            raise IndexError(f"batch index outside [0, {n})")
+        idx = idx.to(self.device, torch.int64)
+        return self.images.gather(idx), self.masks.gather(idx)
+
+    def slice(self, lo, hi):
+        return self.batch(torch.arange(lo, min(hi, len(self)), dtype=torch.int64, device=self.device))

@@ -22,6 +22,7 @@ import torch.nn as nn
 from . import _lib
 from .model_utils import create_unet, create_lunext
 from .cl_dice import soft_dice_cldice
+from .data import DeviceDataset
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -156,14 +157,6 @@ def _device(device):
     return dev
 
 
-def _to_nchw(array, dev):
-    """[N,H,W,C] host array -> fp32 NCHW tensor on the device (training_utils.py:52-55)."""
-    t = torch.as_tensor(np.ascontiguousarray(array), dtype=torch.float32)
-    if t.dim() == 3:
-        t = t.unsqueeze(-1)
-    return t.to(dev, non_blocking=True).permute(0, 3, 1, 2).contiguous()
-
-
 def confusion_counts(logits, masks, counts, per_sample=False):
     """counts (int64, device): [4] (or [b,4] with per_sample) += tp, tn, fp, fn of sigmoid(logits) > 0.5 against
     the masks.  logits and masks: same number of elements, fp32, on the device."""
@@ -212,8 +205,9 @@ def train_model(train_data, validation_data, model_type="UNet", epochs=50, batch
     train_images, train_masks = train_data
     val_images, val_masks = validation_data
     in_channels = train_images.shape[-1] if len(train_images) > 0 else 3       # training_utils.py:87
-    x_tr, m_tr = _to_nchw(train_images, dev), _to_nchw(train_masks, dev)
-    x_va, m_va = _to_nchw(val_images, dev), _to_nchw(val_masks, dev)
+    # the data set goes to the device once, in the loaders' layout (bytes where exact); batches are gathered there
+    ds_tr = DeviceDataset(train_images, train_masks, dev)
+    ds_va = DeviceDataset(val_images, val_masks, dev)
     if model_type == "UNet":
         model = create_unet(in_channels=in_channels, out_channels=1)
         save_path = model_save_path or "best_unet_model.pth"
@@ -257,7 +251,7 @@ def train_model(train_data, validation_data, model_type="UNet", epochs=50, batch
         world = torch.distributed.get_world_size() if joined else 1
     scheduler = PlateauLR(get_lr, set_lr, patience=5, factor=0.5)
 
-    n_train, n_val = len(x_tr), len(x_va)
+    n_train, n_val = len(ds_tr), len(ds_va)
     log(f"training {model_type}: {n_train} training / {n_val} validation samples, batch {batch_size}, lr {learning_rate}")
 
     def train_epoch(epoch):
@@ -265,8 +259,7 @@ def train_model(train_data, validation_data, model_type="UNet", epochs=50, batch
         total = torch.zeros((), dtype=torch.float64, device=dev)
         n_batches = 0
         for i in range(0, len(perm), batch_size):
-            idx = perm[i:i + batch_size]
-            total += train_step(x_tr[idx], m_tr[idx]).double()
+            total += train_step(*ds_tr.batch(perm[i:i + batch_size])).double()
             n_batches += 1
         return total.item() / max(n_batches, 1)
 
@@ -281,7 +274,8 @@ def train_model(train_data, validation_data, model_type="UNet", epochs=50, batch
         n_batches = 0
         with torch.no_grad():
             for i in range(0, n_val, batch_size):
-                total += loss_fn(model(x_va[i:i + batch_size]), m_va[i:i + batch_size]).double()
+                xb, mb = ds_va.slice(i, i + batch_size)
+                total += loss_fn(model(xb), mb).double()
                 n_batches += 1
         return total.item() / max(n_batches, 1)
 
@@ -311,11 +305,10 @@ def evaluate_model(model, data, device=None, batch_size=8):
     chunk = min(100, total)                                 # k_fold.py:261
     with torch.no_grad():
         for i in range(0, total, max(chunk, 1)):
-            x = _to_nchw(images[i:i + chunk], dev)
-            m = torch.as_tensor(np.ascontiguousarray(masks[i:i + chunk]), dtype=torch.float32).to(dev)
-            for j in range(0, len(x), batch_size):
-                logits = model(x[j:j + batch_size])
-                confusion_counts(logits, m[j:j + batch_size], counts)
+            ds = DeviceDataset(images[i:i + chunk], masks[i:i + chunk], dev)
+            for j in range(0, len(ds), batch_size):
+                x, m = ds.slice(j, j + batch_size)
+                confusion_counts(model(x), m, counts)
     tp, tn, fp, fn = counts.cpu().tolist()
     return metrics_from_counts(tp, tn, fp, fn)
 
@@ -336,16 +329,17 @@ def save_results(model, test_data, train_time, filepath, batch_size=1, log=print
     if n == 0:
         log("warning: no test data")
         return None
-    x, m = _to_nchw(test_images, dev), _to_nchw(test_masks, dev)
+    ds = DeviceDataset(test_images, test_masks, dev)
     counts = torch.zeros(n, 4, dtype=torch.int64, device=dev)
     loss_sum = torch.zeros((), dtype=torch.float64, device=dev)
     criterion = nn.BCEWithLogitsLoss()
     num_batches = 0
     with torch.no_grad():
         for i in range(0, n, batch_size):
-            logits = model(x[i:i + batch_size])
-            loss_sum += criterion(logits, m[i:i + batch_size]).double()
-            confusion_counts(logits, m[i:i + batch_size], counts[i:i + batch_size], per_sample=True)
+            xb, mb = ds.slice(i, i + batch_size)
+            logits = model(xb)
+            loss_sum += criterion(logits, mb).double()
+            confusion_counts(logits, mb, counts[i:i + batch_size], per_sample=True)
             num_batches += 1
     per = sample_metrics_from_counts(counts.cpu().numpy())
     avg = {k: float(per[k].sum() / n) for k in SAMPLE_KEYS}
