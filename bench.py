@@ -48,14 +48,15 @@ def cpu_baseline(threads):
         times.append(time.perf_counter() - t0)
     t = sorted(times[1:])[1]                 # median of the 3 timed steps (first is warm-up)
     return {"value": round(4 / t, 3), "unit": "img/s", "cores": threads, "kind": "port",
-            "sample": "4 images 3x256x256 per step (1/8 of the GPU batch), fp32, 1 warm-up + 3 timed steps, median"}
+            "sample": "4 images 3x256x256 per step (batch 4, 1/8 of the GPU batch), fp32, 1 warm-up + 3 timed steps, median"}
 
 
+TRAFFIC_FILE = "r02_traffic.json"   # PMC passes of the kernels in this tree (scratch/prof_round.sh writes it)
 PEAK_HBM = 8.0e12             # MI355X HBM3E, B/s
 CLDICE_BYTES_PER_PIXEL = 592   # both skeletons forward + the prediction's backward + the reductions, fp32, each plane once per pass
 
 
-def lunext_main(args):
+def lunext_result(args, with_cpu_baseline):
     """BASELINE configs[2]: LUNeXt 3x256x256, batch 32, soft_dice_cldice loss, one GPU.  The model's kernels are
     HBM-bound; `roofline` prices the clDice loss (forward + backward) against the HBM peak."""
     import torch
@@ -110,8 +111,7 @@ def lunext_main(args):
                         "achieved": round(achieved / 1e9, 1), "peak": PEAK_HBM / 1e9, "unit": "GB/s",
                         "frac": round(achieved / PEAK_HBM, 4), "traffic": None,
                         "ms_per_call": round(t_loss * 1e3, 3), "bytes_per_pixel": CLDICE_BYTES_PER_PIXEL}}
-    if not args.no_cpu_baseline:
-        import torch.nn as nn  # noqa: F401
+    if with_cpu_baseline:
         threads = int(os.environ.get("OMP_NUM_THREADS", min(16, os.cpu_count() or 1)))
         torch.set_num_threads(threads)
         torch.manual_seed(0)
@@ -127,8 +127,9 @@ def lunext_main(args):
             ropt.step()
             times.append(time.perf_counter() - t1)
         out["cpu_baseline"] = {"value": round(8 / sorted(times[1:])[0], 3), "unit": "img/s", "cores": threads, "kind": "port",
-                               "sample": "8 images 3x256x256 per step, fp32, 1 warm-up + 2 timed steps, best"}
-    print(json.dumps(out), flush=True)
+                               "sample": "8 images 3x256x256 per step (batch 8, 1/4 of the GPU batch), fp32, "
+                                         "1 warm-up + 2 timed steps, best"}
+    return out
 
 
 def main():
@@ -139,13 +140,16 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="images per GPU")
     ap.add_argument("--size", type=int, default=IMG)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-second-workload", action="store_true",
+                    help="leave BASELINE configs[2] (LUNeXt + clDice) out of the line a one-GPU run prints")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank path where RCCL cannot run, e.g. several ranks sharing one GPU)")
     ap.add_argument("--workload", choices=["unet", "lunext"], default="unet",
                     help="unet: BASELINE configs[1] (the contract line); lunext: configs[2], LUNeXt + clDice loss")
     args = ap.parse_args()
     if args.workload == "lunext":
-        return lunext_main(args)
+        print(json.dumps(lunext_result(args, not args.no_cpu_baseline)), flush=True)
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -196,18 +200,21 @@ def main():
     for _ in range(args.warmup):
         trainer.train_step(x, m)
     barrier()
-    # Per-kernel event timing brackets every MFMA launch with two event records (~11 us of stream bubbles per
-    # launch, ~100 launches per step), so only the last few steps of the timed region carry it.
-    timer = KernelTimer()
-    instrumented = min(5, args.steps)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        trainer.timer = timer if i >= args.steps - instrumented else None
         loss = trainer.train_step(x, m)
     barrier()
     dt = time.perf_counter() - t0
+    # After the timed region: per-kernel event timing.  It brackets every MFMA launch with two event records (~11 us of
+    # stream bubbles per launch, ~100 launches per step), so the steps that carry it are not the ones `value` is from.
+    timer = KernelTimer()
+    instrumented = 5
+    trainer.timer = timer
+    for _ in range(instrumented):
+        trainer.train_step(x, m)
+    torch.cuda.synchronize()
     trainer.timer = None
-    # After the timed region: the same kernels with everything on one stream.  In the step the weight gradients run
+    # Then the same kernels with everything on one stream.  In the step the weight gradients run
     # on a second stream beside the input-gradient and BatchNorm kernels, which shortens the step but stretches every
     # overlapped launch; these extra steps give each kernel's rate when it has the chip to itself.
     serial = KernelTimer()
@@ -243,7 +250,7 @@ def main():
         # HBM-side bytes per launch of the dominant kernel: measured separately with rocprofv3 PMC passes (the
         # profiler cannot run inside this process); only valid for the default workload size
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
         if os.path.exists(tpath) and args.size == IMG and args.batch == BATCH_PER_GPU:
             with open(tpath) as fh:
                 traffic = json.load(fh)["kernels"]["conv_band_kernel"]["traffic_bytes_per_launch"]
@@ -260,7 +267,8 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "conv_band_kernel (all 3x3 convolutions: 17 forward + 17 input-gradient launches per step)",
                          "achieved": round(achieved, 1), "peak": PEAK_BF16_DENSE / 1e12, "unit": "TFLOP/s",
                          "frac": round(achieved * 1e12 / PEAK_BF16_DENSE, 4), "traffic": traffic,
-                         "traffic_unit": "bytes per launch (L2 memory-side reads + writes, profiles/r01_traffic.json)",
+                         "traffic_unit": "bytes per launch (L2 memory-side reads + writes: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                         "passes of this command, profiles/" + TRAFFIC_FILE + ")",
                          "launches_per_step": g["launches"] // instrumented, "event_timed_steps": instrumented,
                          "avg_launch_us": round(g["ms"] * 1e3 / g["launches"], 1),
                          "achieved_one_stream": round(ss["conv_band"]["flops"] / (ss["conv_band"]["ms"] * 1e-3) / 1e12, 1),
@@ -278,6 +286,11 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(min(16, os.cpu_count() or 1) if "OMP_NUM_THREADS" not in os.environ
                                                else int(os.environ["OMP_NUM_THREADS"]))
+        if world == 1 and not args.no_second_workload and args.size == IMG and args.batch == BATCH_PER_GPU:
+            # BASELINE configs[2] rides in the same line: LUNeXt + clDice loss on the same GPU, measured right here
+            del trainer, model
+            torch.cuda.empty_cache()
+            out["config2_lunext_cldice"] = lunext_result(args, not args.no_cpu_baseline)
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()
