@@ -52,3 +52,17 @@ def test_product_path_does_not_import_the_oracle():
             if f.endswith(".py"):
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+
+
+def test_host_side_of_the_c_abi_under_address_sanitizer():
+    """`make asan` builds the library with its HOST code instrumented by AddressSanitizer (device code as usual) and a
+    plain C++ driver (tests/asan_driver.cpp) that walks the host paths no GPU is needed for: size and count functions,
+    argument validation of the launching entry points, the thread-local error buffer from several threads."""
+    import subprocess
+    csrc = os.path.join(ROOT, "unet_amd", "csrc")
+    r = subprocess.run(["make", "-C", csrc, "asan", "-j8"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:verify_asan_link_order=0")
+    r = subprocess.run([os.path.join(ROOT, "tests", "asan_driver")], capture_output=True, text=True, timeout=300, env=env)
+    assert "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
+    assert r.returncode == 0 and "ASAN WALK OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

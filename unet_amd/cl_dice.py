@@ -63,9 +63,10 @@ class SoftSkeletonize(nn.Module):
     """cl_dice.py:5-50.  The HIP kernel is built for num_iter = 10, the only value the reference instantiates
     (cl_dice.py:57,103); forward only (the differentiable path is soft_dice_cldice / soft_cldice)."""
 
-    def __init__(self, num_iter=40):
+    def __init__(self, num_iter=40, check_range=True):
         super().__init__()
         self.num_iter = num_iter
+        self.check_range = check_range       # soft_skel validates its input's range (a device read-back) unless False
 
     def _morph(self, img, which):
         planes, H, W = _planes(img, "img")
@@ -91,8 +92,13 @@ class SoftSkeletonize(nn.Module):
             raise NotImplementedError("the soft-skeleton kernel is built for num_iter=10")
         planes, H, W = _planes(img, "img")
         x = img.detach().float().contiguous()
-        if x.numel() and (x.min() < 0 or x.max() > 1):
-            raise NotImplementedError("the soft-skeleton kernel takes inputs in [0,1] (it clamps, as the loss does)")
+        if self.check_range and x.numel():
+            # The kernel clamps to [0, 1] like the loss (cl_dice.py:116-117); the reference's stand-alone module does
+            # not, so values outside that range are refused rather than silently changed.  One fused reduction and one
+            # read-back; SoftSkeletonize(check_range=False) skips both (the loss path never comes through here).
+            lo, hi = torch.aminmax(x)
+            if lo.item() < 0 or hi.item() > 1:
+                raise NotImplementedError("the soft-skeleton kernel takes inputs in [0,1] (it clamps, as the loss does)")
         out = torch.empty_like(x)
         ws = torch.empty(lib.uh_soft_skel_workspace(planes, H, W) // 4, dtype=torch.float32, device=x.device)
         call("uh_soft_skel", planes, H, W, x.data_ptr(), out.data_ptr(), ws.data_ptr(), _stream())

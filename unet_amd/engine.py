@@ -31,6 +31,30 @@ def fuse_bn_bwd():
 _SIDE_STREAMS = {}
 
 
+# UNET_AMD_ROCTX=1: every layer's launches are bracketed by a roctx range ("fwd/conv3_1", "bwd/conv3_1", ...), which
+# rocprofv3 --marker-trace / the torch profiler show beside the kernel trace.  Off by default (two host calls per layer).
+ROCTX = os.environ.get("UNET_AMD_ROCTX", "0") == "1"       # read once, at import
+_NO_RANGE = contextlib.nullcontext()
+
+
+def layer_range(name):
+    return torch.cuda.nvtx.range(name) if ROCTX else _NO_RANGE
+
+
+def ranged(label):
+    """Method decorator: label(*args) names a roctx range around the call; the method is returned as it is when
+    ranges are off."""
+    def deco(fn):
+        if not ROCTX:
+            return fn
+
+        def wrapped(self, *args, **kwargs):
+            with torch.cuda.nvtx.range(label(*args)):
+                return fn(self, *args, **kwargs)
+        return wrapped
+    return deco
+
+
 def side_stream_for(device):
     """The second stream of a device (one per process and device).
 
@@ -168,6 +192,10 @@ class UNetRun:
 
     def _cbr(self, name, a_in, lvl, a_out):
         """conv3x3 + BN + ReLU (unet.py:99 etc.).  a_in is None for the first layer (reads self.x)."""
+        with layer_range("fwd/" + name):
+            return self._cbr_launch(name, a_in, lvl, a_out)
+
+    def _cbr_launch(self, name, a_in, lvl, a_out):
         conv = getattr(self.m, name)
         bn = getattr(self.m, name.replace("conv", "bn", 1))
         B, H, W = self.geo[lvl]
@@ -243,9 +271,10 @@ class UNetRun:
             Bs, Hs, Ws = self.geo[l + 1]
             wp = self.wf[f"upconv{k}"]                        # GEMM rows n = (a*2+b)*Cout + co
             dst = cat[l].window(w, w)
-            self._gemm(Bs, Hs, Ws, cur.ptr, cur.cstride, cur.coff, 2 * w, wp.data_ptr(), 4 * w, 1,
-                 EPI_CONVT, dst.ptr, dst.cstride, dst.coff, up.bias.data_ptr(), None, None, None,
-                 self.masks[l + 1].data_ptr(), s)
+            with layer_range(f"fwd/upconv{k}"):
+                self._gemm(Bs, Hs, Ws, cur.ptr, cur.cstride, cur.coff, 2 * w, wp.data_ptr(), 4 * w, 1,
+                           EPI_CONVT, dst.ptr, dst.cstride, dst.coff, up.bias.data_ptr(), None, None, None,
+                           self.masks[l + 1].data_ptr(), s)
             acts[f"upconv{k}_in"] = cur
             B, H, W = self.geo[l]
             a1 = L.act(B, H, W, w)
@@ -282,6 +311,10 @@ class UNetRun:
     def _cbr_backward(self, name, lvl, da, grads, want_dgrad=True, stats_for=None):
         """Backward of conv3x3+BN+ReLU.  `da` = gradient w.r.t. the layer's activated output.
         Returns the gradient w.r.t. the layer's input activation (an Act with a_in's channel count)."""
+        with layer_range("bwd/" + name):
+            return self._cbr_backward_launch(name, lvl, da, grads, want_dgrad, stats_for)
+
+    def _cbr_backward_launch(self, name, lvl, da, grads, want_dgrad, stats_for):
         rec = self.recs[name]
         conv = getattr(self.m, name)
         L, s = self.lease, _stream()

@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from . import _lib
 from ._lib import call, EPI_RAW_STATS, EPI_AFFINE_RELU, EPI_MASKED, EPI_CONVT
-from .engine import BN_EPS, BN_MOMENTUM, _stream, side_stream_for
+from .engine import BN_EPS, BN_MOMENTUM, _stream, side_stream_for, ranged
 from .layout import pool_for
 from .packing import lunext_packer_for
 
@@ -65,6 +65,7 @@ class LUNeXtRun:
         self.wf = None
 
     # ------------------------------------------------------------------ depthwise block
+    @ranged(lambda name, *a: "fwd/" + name)
     def _dw(self, name, x, lvl):
         blk = getattr(self.m, name)
         B, H, W = self.geo[lvl]
@@ -104,6 +105,7 @@ class LUNeXtRun:
         self.recs[name] = rec
         return a
 
+    @ranged(lambda name, *a: "bwd/" + name)
     def _dw_backward(self, name, da, grads):
         rec = self.recs[name]
         B, H, W = self.geo[rec.lvl]
@@ -139,6 +141,7 @@ class LUNeXtRun:
         return dx
 
     # ------------------------------------------------------------------ 2x2 stride-2 conv (lunext.py:139-154)
+    @ranged(lambda l, *a: f"fwd/downconv{l + 1}")
     def _down(self, l, x):
         """level l-1 -> level l"""
         conv = getattr(self.m, f"downconv{l}")
@@ -155,6 +158,7 @@ class LUNeXtRun:
         self.saved[f"down{l}"] = (x4, K, cpi)
         return out
 
+    @ranged(lambda l, *a: f"bwd/downconv{l + 1}")
     def _down_backward(self, l, dy, grads):
         conv = getattr(self.m, f"downconv{l}")
         x4, K, cpi = self.saved[f"down{l}"]
@@ -182,6 +186,7 @@ class LUNeXtRun:
         return dx
 
     # ------------------------------------------------------------------ transposed conv (lunext.py:161-179)
+    @ranged(lambda k, *a: f"fwd/upconv{k}")
     def _up(self, k, x):
         """level 5-k -> level 4-k"""
         l = 4 - k
@@ -198,6 +203,7 @@ class LUNeXtRun:
         self.saved[f"up{k}"] = (x, N)
         return out
 
+    @ranged(lambda k, *a: f"bwd/upconv{k}")
     def _up_backward(self, k, dup, grads):
         l = 4 - k
         up = getattr(self.m, f"upconv{k}")
@@ -256,6 +262,7 @@ class LUNeXtRun:
         return out
 
     # ------------------------------------------------------------------ attention gate (lunext.py:76-122)
+    @ranged(lambda k, *a: f"fwd/att{k}")
     def _gate(self, k, g, x):
         att = getattr(self.m, f"att{k}")
         l = 4 - k
@@ -288,6 +295,7 @@ class LUNeXtRun:
         self.saved[f"att{k}"] = (g, x, ssum, z)
         return out
 
+    @ranged(lambda k, *a: f"bwd/att{k}")
     def _gate_backward(self, k, dout, grads):
         """returns (dg, dx)"""
         att = getattr(self.m, f"att{k}")
