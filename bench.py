@@ -51,7 +51,7 @@ def cpu_baseline(threads):
             "sample": "4 images 3x256x256 per step (batch 4, 1/8 of the GPU batch), fp32, 1 warm-up + 3 timed steps, median"}
 
 
-TRAFFIC_FILE = "r02_traffic.json"   # PMC passes of the kernels in this tree (scratch/prof_round.sh writes it)
+TRAFFIC_FILE = "r02_traffic.json"   # PMC passes of the kernels in this tree (tools/prof_round.sh writes it)
 PEAK_HBM = 8.0e12             # MI355X HBM3E, B/s
 CLDICE_BYTES_PER_PIXEL = 592   # both skeletons forward + the prediction's backward + the reductions, fp32, each plane once per pass
 

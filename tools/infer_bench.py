@@ -1,6 +1,6 @@
 """Evaluation path throughput (eval-mode U-Net forward + on-device confusion counts), the reference's inference
 shapes: batch 1 at 1024^2 (test_helper/utils.py:116-125) and batch 8 at 256^2 (k_fold.py:281-290).
-python scratch/infer_bench.py"""
+python tools/infer_bench.py"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

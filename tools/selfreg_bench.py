@@ -1,5 +1,5 @@
 """Cost of the self-regularisation loss at the bench size (U-Net, batch 32, 256 x 256): the auxiliaries alone, and
-the training step with it against the BCE step.  python scratch/selfreg_bench.py"""
+the training step with it against the BCE step.  python tools/selfreg_bench.py"""
 import json
 import sys
 import os

@@ -6,6 +6,6 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $out/rp -o t -- python3 $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-second-workload > $out/bench.json 2> $out/err.log || exit 1
 cd $GRAFT_REPO_ROOT
 f=$(find $out/rp -name "*kernel_trace.csv" | head -1)
-python scratch/timeline.py $f full 6 > $out/timeline2.txt
+python tools/timeline.py $f full 6 > $out/timeline2.txt
 tail -1 $out/timeline2.txt
 rm -rf $out/rp
