@@ -37,6 +37,20 @@ def _padv(t, n, fill=0.0):
     return out
 
 
+class _Handle:
+    """context manager that just hands out a stream handle"""
+    __slots__ = ("h",)
+
+    def __init__(self, h):
+        self.h = h
+
+    def __enter__(self):
+        return self.h
+
+    def __exit__(self, *exc):
+        return False
+
+
 class _DWRec:
     __slots__ = ("name", "x", "y", "a", "C", "Cp", "lvl", "wt", "mean", "invstd", "scale", "shift")
 
@@ -70,7 +84,7 @@ class LUNeXtRun:
         blk = getattr(self.m, name)
         B, H, W = self.geo[lvl]
         C, Cp = blk.depthwise.out_channels, x.C
-        s, Ls = _stream(), self.lease
+        s, Ls = self._sh, self.lease
         wt, bias = blk.depthwise.weight.detach(), blk.depthwise.bias.detach()      # read in place by the kernels
         if wt.data_ptr() % 16 or not wt.is_contiguous():
             wt = wt.clone(memory_format=torch.contiguous_format)
@@ -110,7 +124,7 @@ class LUNeXtRun:
         rec = self.recs[name]
         B, H, W = self.geo[rec.lvl]
         C, Cp, x, y = rec.C, rec.Cp, rec.x, rec.y
-        s, Ls = _stream(), self.lease
+        s, Ls = self._sh, self.lease
         mask = self.masks[rec.lvl]
         parts = L.uh_bn_bwd_parts(x.Mp, Cp)
         partial = Ls.f32(parts * 2 * Cp)
@@ -148,7 +162,7 @@ class LUNeXtRun:
         cin, cpi, cout = self.chans[l - 1], x.C, self.chans[l]
         Bs, Hs, Ws = self.geo[l]
         K = max(64, 4 * cpi)
-        s, Ls = _stream(), self.lease
+        s, Ls = self._sh, self.lease
         x4 = Ls.act(Bs, Hs, Ws, K, tag=f"down{l}.x4")
         call("uh_space_to_depth2", Bs, Hs, Ws, cpi, x.ptr, x.cstride, x.coff, x4.ptr, x4.cstride, 0, s)
         wp = self.wf[f"down{l}"]
@@ -164,7 +178,7 @@ class LUNeXtRun:
         x4, K, cpi = self.saved[f"down{l}"]
         cin, cout = self.chans[l - 1], self.chans[l]
         Bs, Hs, Ws = self.geo[l]
-        s, Ls = _stream(), self.lease
+        s, Ls = self._sh, self.lease
         grads[f"downconv{l}.bias"] = self._colsum(dy, cout)
         S = L.uh_conv_wgrad_splits(Bs, Hs, Ws, cout, K, 1)
         part = Ls.f32(S * cout * K)
@@ -194,7 +208,7 @@ class LUNeXtRun:
         cin, cout, cpo = self.chans[l + 1], self.chans[l], self.cp[l]
         N = max(64, 4 * cpo)
         Bs, Hs, Ws = self.geo[l + 1]
-        s, Ls = _stream(), self.lease
+        s, Ls = self._sh, self.lease
         wp = self.wf[f"up{k}"]
         out = Ls.act(*self.geo[l], cpo)
         bias = _padv(up.bias, cpo)
@@ -210,7 +224,7 @@ class LUNeXtRun:
         x, N = self.saved[f"up{k}"]
         cin, cout, cpo = self.chans[l + 1], self.chans[l], self.cp[l]
         Bs, Hs, Ws = self.geo[l + 1]
-        s, Ls = _stream(), self.lease
+        s, Ls = self._sh, self.lease
         grads[f"upconv{k}.bias"] = self._colsum(dup, cpo)[:cout]           # a view of a tensor made for this gradient
         d4 = Ls.act(Bs, Hs, Ws, N, tag=f"up{k}.d4")
         call("uh_space_to_depth2", Bs, Hs, Ws, cpo, dup.ptr, dup.cstride, dup.coff, d4.ptr, d4.cstride, 0, s)
@@ -228,20 +242,27 @@ class LUNeXtRun:
              dx.cstride, dx.coff, None, None, None, None, self.masks[l + 1].data_ptr(), s)
         return dx
 
-    @contextlib.contextmanager
+    def _bind_streams(self):
+        """Looks the current stream up ONCE per pass (torch.cuda.current_stream() costs ~9 us, and a pass asked for it
+        ~60 times: the LUNeXt step is bound by what the host spends per launch, not by the GPU)."""
+        self._main = torch.cuda.current_stream(self.device)
+        self._sh = self._main.cuda_stream
+        self._two_streams = os.environ.get("UNET_AMD_WGRAD_STREAM", "1") != "0"
+        if self._two_streams:
+            self._side_st = side_stream_for(self.device)
+            self._fork_event = torch.cuda.Event()
+
     def _side(self):
-        """Kernels launched inside run on a second stream, ordered after everything issued so far on the current one
-        (UNET_AMD_WGRAD_STREAM=0: on the current stream).  Only launches into buffers that already exist belong here:
-        memory that torch allocates while another stream is current is recycled on that stream's schedule.
-        backward() joins the stream before it returns."""
-        if os.environ.get("UNET_AMD_WGRAD_STREAM", "1") == "0":
-            yield _stream()
-            return
-        st = side_stream_for(self.device)
-        self._side_used = st
-        st.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(st):
-            yield st.cuda_stream
+        """`with self._side() as s2:` -- kernels launched on s2 run on a second stream, ordered after everything issued
+        so far on the main one (UNET_AMD_WGRAD_STREAM=0: s2 is the main stream).  Only launches into buffers that
+        already exist belong there.  torch's current stream is NOT switched (every launch takes its stream explicitly):
+        no torch operation may sit inside the block.  backward() joins the stream before it returns."""
+        if not self._two_streams:
+            return _Handle(self._sh)
+        self._side_used = self._side_st
+        self._fork_event.record(self._main)
+        self._side_st.wait_event(self._fork_event)
+        return _Handle(self._side_st.cuda_stream)
 
     def _zeros(self, n):
         """n zeros out of one per-run buffer (gradients that are identically zero; nothing writes to them)."""
@@ -253,7 +274,7 @@ class LUNeXtRun:
         return out
 
     def _colsum(self, a, C):
-        s, Ls = _stream(), self.lease
+        s, Ls = self._sh, self.lease
         parts = L.uh_colsum_parts(a.Mp, C)
         cp = Ls.f32(parts * C)
         call("uh_colsum", a.Mp, C, a.ptr, a.cstride, a.coff, cp.data_ptr(), s)
@@ -268,7 +289,7 @@ class LUNeXtRun:
         l = 4 - k
         B, H, W = self.geo[l]
         C, Cp = self.chans[l], g.C
-        s, Ls = _stream(), self.lease
+        s, Ls = self._sh, self.lease
         out = Ls.act(B, H, W, Cp)
         if Cp == 8:
             wts = Ls.f32(216)
@@ -302,7 +323,7 @@ class LUNeXtRun:
         l = 4 - k
         B, H, W = self.geo[l]
         C = self.chans[l]
-        s, Ls = _stream(), self.lease
+        s, Ls = self._sh, self.lease
         pre = f"att{k}."
         if self.cp[l] == 8 and C < 64:
             g, x, wts = self.saved[f"att{k}"]
@@ -357,7 +378,8 @@ class LUNeXtRun:
 
     # ------------------------------------------------------------------ whole network
     def forward(self):
-        m, Ls, s = self.m, self.lease, _stream()
+        self._bind_streams()
+        m, Ls, s = self.m, self.lease, self._sh
         self.wf = self.packer.get("fwd", s)
         B, H, W = self.geo[0]
         cin = self.chans[0]
@@ -387,7 +409,8 @@ class LUNeXtRun:
     def backward(self, dlogits):
         if not self.training:
             raise RuntimeError("backward through an eval-mode forward is not built; call model.train() first")
-        m, Ls, s = self.m, self.lease, _stream()
+        self._bind_streams()
+        m, Ls, s = self.m, self.lease, self._sh
         self.wb = self.packer.get("bwd", s)
         grads = {}
         B, H, W = self.geo[0]
@@ -421,7 +444,7 @@ class LUNeXtRun:
                  tot.ptr, tot.cstride, tot.coff, s)
             da = self._dw_backward(f"conv{l}_1", self._dw_backward(f"conv{l}_2", tot, grads), grads)
         if self._side_used is not None:
-            torch.cuda.current_stream().wait_stream(self._side_used)
+            self._main.wait_stream(self._side_used)
         return grads
 
     def release(self):
@@ -436,7 +459,7 @@ class _LUNeXtFn(torch.autograd.Function):
         run = LUNeXtRun(module, x, training=True)
         logits = run.forward()
         ctx.run = run
-        ctx.names = [n for n, _ in module.named_parameters()]
+        ctx.names = module._param_names()
         return logits
 
     @staticmethod
@@ -494,6 +517,12 @@ class LUNeXt(nn.Module):
             setattr(self, f"conv_up{k}_1", _DWParams(co))
             setattr(self, f"conv_up{k}_2", _DWParams(co))
         self.final_conv = nn.Conv2d(in_channels, out_channels, kernel_size=1)
+
+    def _param_names(self):
+        names = self.__dict__.get("_names_cache")
+        if names is None:
+            names = self.__dict__["_names_cache"] = [n for n, _ in self.named_parameters()]
+        return names
 
     def forward(self, x):
         if not x.is_cuda:
