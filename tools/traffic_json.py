@@ -1,4 +1,4 @@
-"""profiles/r01_traffic.json from the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of bench.py"""
+"""profiles/rNN_traffic.json from the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of bench.py"""
 import csv, json, sys, collections
 fetch_csv, write_csv, out = sys.argv[1:4]
 def per_kernel(path, counter):
