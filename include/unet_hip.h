@@ -175,6 +175,19 @@ int uh_maxpool2_bwd(int B, int H, int W, int C, const void* a, int a_cstride, in
                     const void* add, int add_cstride, int add_coff,
                     void* da, int da_cstride, int da_coff, uh_stream s);
 
+/* uh_maxpool2_bwd where da is the gradient at the output of a conv + BatchNorm + ReLU layer (the encoder's conv{l}_2,
+ * whose activation was pooled, unet.py:100-124): also leaves that layer's BatchNorm-backward sums, as
+ * uh_bn_relu_bwd_reduce would compute them from the stored da and the layer's fp16 conv output y, in
+ * partial[uh_maxpool2_bwd_bnstat_parts()][2][C].  C = 8 * a power of two. */
+int uh_maxpool2_bwd_bnstat_parts(int B, int H, int W, int C);
+int uh_maxpool2_bwd_bnstat(int B, int H, int W, int C, const void* a, int a_cstride, int a_coff,
+                           const void* dp, int dp_cstride, int dp_coff,
+                           const void* add, int add_cstride, int add_coff,
+                           void* da, int da_cstride, int da_coff,
+                           const void* y, int y_cstride, int y_coff,
+                           const float* mean, const float* invstd, const float* scale, const float* shift,
+                           float* partial, uh_stream s);
+
 /* ---- space-to-depth 2x2: out[(b,y,x)][t*C + c] = in[(b,2y+t/2,2x+t%2)][c]; in geometry (B,2H,2W) ----
  * Turns the gradient of a k2 s2 transposed conv, and the input of a k2 s2 conv (lunext.py:139-154),
  * into a T=1 GEMM operand. */
@@ -196,6 +209,14 @@ int uh_head_bwd_parts(int B, int H, int W, int C);
 int uh_head_bwd(int B, int H, int W, int C, int OC, const void* a, int a_cstride, int a_coff,
                 const float* w, const float* dlogits_nchw,
                 void* da, int da_cstride, int da_coff, float* partial /*[P][OC][C+1]*/, uh_stream s);
+/* uh_head_bwd that also leaves the BatchNorm-backward sums of the layer in front of the head (conv_up4_2,
+ * unet.py:168-173) in bn_partial[uh_head_bwd_parts()][2][C], as uh_bn_relu_bwd_reduce would compute them */
+int uh_head_bwd_bnstat(int B, int H, int W, int C, int OC, const void* a, int a_cstride, int a_coff,
+                       const float* w, const float* dlogits_nchw,
+                       void* da, int da_cstride, int da_coff, float* partial,
+                       const void* y, int y_cstride, int y_coff,
+                       const float* mean, const float* invstd, const float* scale, const float* shift,
+                       float* bn_partial, uh_stream s);
 
 /* ---- LUNeXt blocks (models/lunext.py), padded-linear NHWC bf16 with C a multiple of 8 ----------------
  * The 3-channel full-resolution level is carried zero-padded to 8 channels. */

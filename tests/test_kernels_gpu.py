@@ -658,6 +658,81 @@ def test_conv_dgrad_with_batchnorm_backward_sums(B, H, W, Cin, Cout):
     assert ((got - sep).abs() <= 4e-3 * ref).all(), "fused sums against the separate pass"
 
 
+def _bn_bwd_setup(g, B, C, H, W):
+    y = (torch.randn(B, C, H, W, generator=g) * 2 + 0.3).half().float()       # the layer's fp16 conv output
+    mean, invstd = torch.randn(C, generator=g) * 0.2, torch.rand(C, generator=g) + 0.5
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g) * 0.3
+    scale = gamma * invstd
+    st = [t.to(DEV) for t in (mean, invstd, scale, beta - mean * scale)]
+    return act_from(y, cstride=C + 64, coff=64, half=True), st
+
+
+def _separate_sums(da, ya, st):
+    C = da.C
+    rparts = lib.uh_bn_bwd_parts(da.Mp, C)
+    rp = torch.empty(rparts, 2, C, device=DEV)
+    call("uh_bn_relu_bwd_reduce", da.Mp, C, da.ptr, da.cstride, da.coff, ya.ptr, ya.cstride, ya.coff,
+         st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(), st[3].data_ptr(), rp.data_ptr(), S())
+    torch.cuda.synchronize()
+    mag = da.to_nchw().abs().sum((0, 2, 3)).cpu().double()
+    return rp.double().sum(0).cpu(), mag
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 8, 8, 64), (1, 4, 12, 128), (3, 2, 2, 512), (2, 64, 48, 64), (1, 2, 2, 1024)])
+def test_maxpool_backward_with_batchnorm_backward_sums(B, H, W, C):
+    """uh_maxpool2_bwd_bnstat writes the same gradient as uh_maxpool2_bwd, bit for bit, and its sums are those of
+    uh_bn_relu_bwd_reduce over that gradient (same inputs, fp32 additions in another order)."""
+    g = torch.Generator().manual_seed(61)
+    x = (torch.randint(0, 4, (B, C, H, W), generator=g).float() / 2)
+    a = act_from(x, cstride=2 * C, coff=C)
+    dpa = act_from(bf(torch.randn(B, C, H // 2, W // 2, generator=g)))
+    adda = act_from(bf(torch.randn(B, C, H, W, generator=g)), cstride=2 * C, coff=0)
+    ya, st = _bn_bwd_setup(g, B, C, H, W)
+    plain, fused = new_act(B, H, W, C, DEV), new_act(B, H, W, C, DEV)
+    fused.buf[fused.guard:fused.guard + fused.Mp] = 9.0
+    call("uh_maxpool2_bwd", B, H, W, C, a.ptr, a.cstride, a.coff, dpa.ptr, dpa.cstride, dpa.coff, adda.ptr,
+         adda.cstride, adda.coff, plain.ptr, plain.cstride, plain.coff, S())
+    parts = lib.uh_maxpool2_bwd_bnstat_parts(B, H, W, C)
+    assert parts >= 1
+    fp = torch.full((parts, 2, C), float("nan"), device=DEV)
+    call("uh_maxpool2_bwd_bnstat", B, H, W, C, a.ptr, a.cstride, a.coff, dpa.ptr, dpa.cstride, dpa.coff, adda.ptr,
+         adda.cstride, adda.coff, fused.ptr, fused.cstride, fused.coff, ya.ptr, ya.cstride, ya.coff,
+         st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(), st[3].data_ptr(), fp.data_ptr(), S())
+    torch.cuda.synchronize()
+    assert torch.equal(plain.buf, fused.buf)
+    pads_are_zero(fused)
+    want, mag = _separate_sums(plain, ya, st)
+    got = fp.double().sum(0).cpu()
+    assert torch.isfinite(got).all()
+    assert ((got - want).abs() <= 1e-5 * mag.max() * 8 + 1e-6).all()
+
+
+@pytest.mark.parametrize("B,H,W,C,OC", [(2, 8, 12, 64, 1), (1, 5, 7, 64, 2), (2, 16, 16, 8, 1)])
+def test_head_backward_with_batchnorm_backward_sums(B, H, W, C, OC):
+    """uh_head_bwd_bnstat: gradient and weight partials as uh_head_bwd, bit for bit; sums as the separate pass."""
+    g = torch.Generator().manual_seed(67)
+    a = act_from(bf(torch.randn(B, C, H, W, generator=g)), cstride=2 * C, coff=C)
+    w = (torch.randn(OC, C, generator=g) / 8).to(DEV)
+    dl = torch.randn(B, OC, H, W, generator=g).to(DEV)
+    ya, st = _bn_bwd_setup(g, B, C, H, W)
+    plain, fused = new_act(B, H, W, C, DEV), new_act(B, H, W, C, DEV)
+    parts = lib.uh_head_bwd_parts(B, H, W, C)
+    hp0, hp1 = torch.empty(parts, OC, C + 1, device=DEV), torch.empty(parts, OC, C + 1, device=DEV)
+    fp = torch.full((parts, 2, C), float("nan"), device=DEV)
+    call("uh_head_bwd", B, H, W, C, OC, a.ptr, a.cstride, a.coff, w.data_ptr(), dl.data_ptr(), plain.ptr,
+         plain.cstride, plain.coff, hp0.data_ptr(), S())
+    call("uh_head_bwd_bnstat", B, H, W, C, OC, a.ptr, a.cstride, a.coff, w.data_ptr(), dl.data_ptr(), fused.ptr,
+         fused.cstride, fused.coff, hp1.data_ptr(), ya.ptr, ya.cstride, ya.coff, st[0].data_ptr(), st[1].data_ptr(),
+         st[2].data_ptr(), st[3].data_ptr(), fp.data_ptr(), S())
+    torch.cuda.synchronize()
+    assert torch.equal(plain.buf, fused.buf) and torch.equal(hp0, hp1)
+    pads_are_zero(fused)
+    want, mag = _separate_sums(plain, ya, st)
+    got = fp.double().sum(0).cpu()
+    assert torch.isfinite(got).all()
+    assert ((got - want).abs() <= 1e-5 * mag.max() * 8 + 1e-6).all()
+
+
 # ---- AttentionGate kernels (lunext.py:76-122) ---------------------------------------------------------------------
 @pytest.mark.parametrize("B,H,W,C", [(2, 8, 8, 64), (1, 6, 10, 128), (2, 4, 4, 256)])
 def test_gate_pointwise_forward_backward(B, H, W, C):

@@ -59,6 +59,9 @@ SIGNATURES = {
     "uh_colsum_finalize": (I, [P, I, I, I, P, I, P]),
     "uh_head_fwd": (I, [I, I, I, I, I, P, I, I, P, P, P, P]),
     "uh_head_bwd_parts": (I, [I, I, I, I]),
+    "uh_head_bwd_bnstat": (I, [I, I, I, I, I, P, I, I, P, P, P, I, I, P, P, I, I, P, P, P, P, P, P]),
+    "uh_maxpool2_bwd_bnstat_parts": (I, [I, I, I, I]),
+    "uh_maxpool2_bwd_bnstat": (I, [I, I, I, I, P, I, I, P, I, I, P, I, I, P, I, I, P, I, I, P, P, P, P, P, P]),
     "uh_head_bwd": (I, [I, I, I, I, I, P, I, I, P, P, P, I, I, P, P]),
     "uh_dw_parts": (I, [I, I, I, I]),
     "uh_dwconv3x3_fwd": (I, [I, I, I, I, P, I, I, P, I, P, I, P, P, P, P, I, I, P, P]),

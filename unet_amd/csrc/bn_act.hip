@@ -383,13 +383,42 @@ extern "C" int uh_maxpool2_fwd(int B, int H, int W, int C, const void* a, int a_
   return uh_check_launch("maxpool2_fwd");
 }
 
+// STATS: `da` is the gradient at the output of a conv + BatchNorm + ReLU layer (conv{l}_2, whose activation `a` was
+// pooled): the layer's BatchNorm-backward sums (what bn_relu_bwd_reduce_kernel computes from da and the layer's fp16
+// conv output y in a pass of its own) are taken here, from the values as they are stored (after rounding to bf16).
+struct PoolBnStat {
+  const char* y;
+  int y_cs, y_co;
+  const float* mean;
+  const float* invstd;
+  const float* scale;
+  const float* shift;
+  float* partial;                   // [gridDim.x][2][C]
+};
+
+template <bool STATS>
 __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(int B, int H, int W, int C, const char* __restrict__ a,
                                                            int a_cs, int a_co, const char* __restrict__ dp, int dp_cs,
                                                            int dp_co, const char* __restrict__ add, int add_cs,
-                                                           int add_co, char* __restrict__ da, int da_cs, int da_co) {
+                                                           int add_co, char* __restrict__ da, int da_cs, int da_co,
+                                                           PoolBnStat st) {
+  extern __shared__ float lds[];
   const int oH = H / 2, oW = W / 2, oHp = oH + 1, oWp = oW + 1, Wp = W + 1, Hp = H + 1;
   const int cpr = C / 8;
   const long long total = (long long)B * oHp * oWp * cpr;
+  float acc[2][8];
+  float sc[8], sh[8], mu[8], is[8];
+  if (STATS) {
+    const int cc0 = threadIdx.x % cpr;          // 256 % cpr == 0: a thread keeps its channel chunk in every iteration
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      acc[0][j] = acc[1][j] = 0.f;
+      sc[j] = st.scale[cc0 * 8 + j];
+      sh[j] = st.shift[cc0 * 8 + j];
+      mu[j] = st.mean[cc0 * 8 + j];
+      is[j] = st.invstd[cc0 * 8 + j];
+    }
+  }
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int cc = (int)(i % cpr);
     long long r = i / cpr;
@@ -425,7 +454,19 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(int B, int H, int W, 
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] += (idx[j] == k) ? g[j] : 0.f;
-        *(U4*)(da + (mm[k] * da_cs + da_co + cc * 8) * 2) = pack8(o);
+        const U4 packed = pack8(o);
+        *(U4*)(da + (mm[k] * da_cs + da_co + cc * 8) * 2) = packed;
+        if (STATS) {
+          float d8[8], yv[8];
+          unpack8(packed, d8);
+          unpack8h(*(const U4*)(st.y + (mm[k] * st.y_cs + st.y_co + cc * 8) * 2), yv);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float d = (yv[j] * sc[j] + sh[j] > 0.f) ? d8[j] : 0.f;
+            acc[0][j] += d;
+            acc[1][j] += d * (yv[j] - mu[j]) * is[j];
+          }
+        }
       }
     } else {
       // pad position of the pooled grid: zero the pad rows of the input grid it covers
@@ -437,6 +478,7 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(int B, int H, int W, 
       }
     }
   }
+  if (STATS) block_combine_store<2>(acc, C, cpr, 256 / cpr, lds, st.partial + (long long)blockIdx.x * 2 * C);
 }
 
 extern "C" int uh_maxpool2_bwd(int B, int H, int W, int C, const void* a, int a_cstride, int a_coff, const void* dp,
@@ -447,10 +489,37 @@ extern "C" int uh_maxpool2_bwd(int B, int H, int W, int C, const void* a, int a_
   const long long total = uh_mp(B, H / 2, W / 2) * (C / 8);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, B, H, W, C, (const char*)a,
-                     a_cstride, a_coff, (const char*)dp, dp_cstride, dp_coff, (const char*)add, add_cstride, add_coff,
-                     (char*)da, da_cstride, da_coff);
+  hipLaunchKernelGGL((maxpool2_bwd_kernel<false>), dim3(blocks), dim3(256), 0, (hipStream_t)s, B, H, W, C,
+                     (const char*)a, a_cstride, a_coff, (const char*)dp, dp_cstride, dp_coff, (const char*)add,
+                     add_cstride, add_coff, (char*)da, da_cstride, da_coff, PoolBnStat{});
   return uh_check_launch("maxpool2_bwd");
+}
+
+static int pool_bnstat_blocks(int B, int H, int W, int C) {
+  const long long total = uh_mp(B, H / 2, W / 2) * (C / 8);
+  long long blocks = (total + 255) / 256 / 8;        // one row of partial sums per workgroup: at least 8 rounds each
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+extern "C" int uh_maxpool2_bwd_bnstat_parts(int B, int H, int W, int C) {
+  return (B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0) ? pool_bnstat_blocks(B, H, W, C) : 0;
+}
+
+extern "C" int uh_maxpool2_bwd_bnstat(int B, int H, int W, int C, const void* a, int a_cstride, int a_coff,
+                                      const void* dp, int dp_cstride, int dp_coff, const void* add, int add_cstride,
+                                      int add_coff, void* da, int da_cstride, int da_coff, const void* y, int y_cstride,
+                                      int y_coff, const float* mean, const float* invstd, const float* scale,
+                                      const float* shift, float* partial, uh_stream s) {
+  UH_REQUIRE(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "maxpool2_bwd_bnstat: H=%d W=%d must be even", H, W);
+  UH_REQUIRE(C > 0 && C % 8 == 0 && 256 % (C / 8) == 0, "maxpool2_bwd_bnstat: C=%d must be 8 times a power of two <= 2048", C);
+  UH_REQUIRE(a && dp && da && y && mean && invstd && scale && shift && partial, "maxpool2_bwd_bnstat: null pointer");
+  const int blocks = pool_bnstat_blocks(B, H, W, C);
+  PoolBnStat st{(const char*)y, y_cstride, y_coff, mean, invstd, scale, shift, partial};
+  hipLaunchKernelGGL((maxpool2_bwd_kernel<true>), dim3(blocks), dim3(256), (size_t)2 * 256 * 8 * 4, (hipStream_t)s, B, H, W,
+                     C, (const char*)a, a_cstride, a_coff, (const char*)dp, dp_cstride, dp_coff, (const char*)add,
+                     add_cstride, add_coff, (char*)da, da_cstride, da_coff, st);
+  return uh_check_launch("maxpool2_bwd_bnstat");
 }
 
 // ---- 1x1 head: logits[b][oc][y][x] = sum_c a[m][c]*w[oc][c] + bias[oc] ---------------------------------
@@ -510,16 +579,30 @@ static inline int head_bwd_blocks(int B, int H, int W, int C) {
 }
 extern "C" int uh_head_bwd_parts(int B, int H, int W, int C) { return head_c_ok(C) ? head_bwd_blocks(B, H, W, C) : 0; }
 
+// STATS: the head's input is the output of a conv + BatchNorm + ReLU layer; that layer's BatchNorm-backward sums are
+// taken from da as it is stored (see PoolBnStat), into st.partial[gridDim.x][2][C].
+template <bool STATS>
 __global__ __launch_bounds__(256) void head_bwd_kernel(int B, int H, int W, int C, int OC, const char* __restrict__ a,
                                                        int a_cs, int a_co, const float* __restrict__ w,
                                                        const float* __restrict__ dl, char* __restrict__ da, int da_cs,
-                                                       int da_co, float* __restrict__ partial) {
+                                                       int da_co, float* __restrict__ partial, PoolBnStat st) {
   extern __shared__ float lds[];
   const int cpr = C / 8, rpi = 256 / cpr;
   const int rr = threadIdx.x / cpr, cc = threadIdx.x % cpr;
   const int Wp = W + 1, Hp = H + 1;
   const long long Mp = (long long)B * Hp * Wp;
   float* out_row = partial + (long long)blockIdx.x * OC * (C + 1);
+  float bacc[2][8], sc[8], sh[8], mu[8], is[8];
+  if (STATS) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      bacc[0][j] = bacc[1][j] = 0.f;
+      sc[j] = st.scale[cc * 8 + j];
+      sh[j] = st.shift[cc * 8 + j];
+      mu[j] = st.mean[cc * 8 + j];
+      is[j] = st.invstd[cc * 8 + j];
+    }
+  }
   for (int oc = 0; oc < OC; ++oc) {
     // one pass per output channel keeps the register footprint fixed; OC is 1 in practice
     float acc[1][8], dbs = 0.f;
@@ -546,7 +629,21 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(int B, int H, int W, int 
           }
         }
       }
-      if (oc == OC - 1) *(U4*)(da + (m * da_cs + da_co + cc * 8) * 2) = pack8(o);
+      if (oc == OC - 1) {
+        const U4 packed = pack8(o);
+        *(U4*)(da + (m * da_cs + da_co + cc * 8) * 2) = packed;
+        if (STATS && x < W && y < H) {
+          float d8[8], yv[8];
+          unpack8(packed, d8);
+          unpack8h(*(const U4*)(st.y + (m * st.y_cs + st.y_co + cc * 8) * 2), yv);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float d = (yv[j] * sc[j] + sh[j] > 0.f) ? d8[j] : 0.f;
+            bacc[0][j] += d;
+            bacc[1][j] += d * (yv[j] - mu[j]) * is[j];
+          }
+        }
+      }
     }
     __syncthreads();
     block_combine_store<1>(acc, C, cpr, rpi, lds, out_row + oc * (C + 1));
@@ -560,6 +657,10 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(int B, int H, int W, int 
       out_row[oc * (C + 1) + C] = v;
     }
   }
+  if (STATS) {
+    __syncthreads();
+    block_combine_store<2>(bacc, C, cpr, rpi, lds, st.partial + (long long)blockIdx.x * 2 * C);
+  }
 }
 
 extern "C" int uh_head_bwd(int B, int H, int W, int C, int OC, const void* a, int a_cstride, int a_coff,
@@ -568,8 +669,26 @@ extern "C" int uh_head_bwd(int B, int H, int W, int C, int OC, const void* a, in
   UH_REQUIRE(B > 0 && H > 0 && W > 0 && OC > 0 && a && w && dlogits && da && partial, "head_bwd: bad arguments");
   UH_REQUIRE(head_c_ok(C), "head_bwd: C=%d must be a power of two in [8,512]", C);
   const int rpi = 256 / (C / 8);
-  hipLaunchKernelGGL(head_bwd_kernel, dim3(head_bwd_blocks(B, H, W, C)), dim3(256), (size_t)rpi * C * 4, (hipStream_t)s,
-                     B, H, W, C, OC, (const char*)a, a_cstride, a_coff, w, dlogits, (char*)da, da_cstride, da_coff,
-                     partial);
+  hipLaunchKernelGGL((head_bwd_kernel<false>), dim3(head_bwd_blocks(B, H, W, C)), dim3(256), (size_t)rpi * C * 4,
+                     (hipStream_t)s, B, H, W, C, OC, (const char*)a, a_cstride, a_coff, w, dlogits, (char*)da, da_cstride,
+                     da_coff, partial, PoolBnStat{});
   return uh_check_launch("head_bwd");
+}
+
+// uh_head_bwd that also leaves the BatchNorm-backward sums of the layer that produced `a` (fp16 conv output y, batch
+// statistics mean/invstd, affine scale/shift) in bn_partial[uh_head_bwd_parts()][2][C].
+extern "C" int uh_head_bwd_bnstat(int B, int H, int W, int C, int OC, const void* a, int a_cstride, int a_coff,
+                                  const float* w, const float* dlogits, void* da, int da_cstride, int da_coff,
+                                  float* partial, const void* y, int y_cstride, int y_coff, const float* mean,
+                                  const float* invstd, const float* scale, const float* shift, float* bn_partial,
+                                  uh_stream s) {
+  UH_REQUIRE(B > 0 && H > 0 && W > 0 && OC > 0 && a && w && dlogits && da && partial, "head_bwd_bnstat: bad arguments");
+  UH_REQUIRE(y && mean && invstd && scale && shift && bn_partial, "head_bwd_bnstat: null pointer");
+  UH_REQUIRE(head_c_ok(C), "head_bwd_bnstat: C=%d must be a power of two in [8,512]", C);
+  const int rpi = 256 / (C / 8);
+  PoolBnStat st{(const char*)y, y_cstride, y_coff, mean, invstd, scale, shift, bn_partial};
+  hipLaunchKernelGGL((head_bwd_kernel<true>), dim3(head_bwd_blocks(B, H, W, C)), dim3(256), (size_t)2 * rpi * C * 4,
+                     (hipStream_t)s, B, H, W, C, OC, (const char*)a, a_cstride, a_coff, w, dlogits, (char*)da, da_cstride,
+                     da_coff, partial, st);
+  return uh_check_launch("head_bwd_bnstat");
 }

@@ -28,6 +28,14 @@ WIDTHS = (64, 128, 256, 512, 1024)
 def fuse_bn_bwd():
     return os.environ.get("UNET_AMD_FUSE_BN_BWD", "0") == "1"
 
+
+
+# UNET_AMD_FUSE_POOL_STATS=0: the BatchNorm-backward sums of conv{l}_2 and conv_up4_2 are taken in a pass of their own
+# (uh_bn_relu_bwd_reduce).  By default the bandwidth-bound kernels that write those layers' output gradients
+# (uh_maxpool2_bwd_bnstat, uh_head_bwd_bnstat) take them on the way: one read of the gradient and one launch less each.
+def fuse_pool_stats():
+    return os.environ.get("UNET_AMD_FUSE_POOL_STATS", "1") == "1"
+
 _SIDE_STREAMS = {}
 
 
@@ -436,8 +444,17 @@ class UNetRun:
         da = L.act(B, H, W, 64)
         parts = _lib.lib.uh_head_bwd_parts(B, H, W, 64)
         hp = L.f32(parts * oc * 65)
-        call("uh_head_bwd", B, H, W, 64, oc, a.ptr, a.cstride, a.coff, fc.weight.data_ptr(), dl.data_ptr(),
-             da.ptr, da.cstride, da.coff, hp.data_ptr(), s)
+        if fuse_pool_stats():
+            rec = self.recs["conv_up4_2"]
+            bp = L.f32(parts * 2 * 64)
+            call("uh_head_bwd_bnstat", B, H, W, 64, oc, a.ptr, a.cstride, a.coff, fc.weight.data_ptr(), dl.data_ptr(),
+                 da.ptr, da.cstride, da.coff, hp.data_ptr(), rec.y.ptr, rec.y.cstride, rec.y.coff,
+                 rec.mean.data_ptr(), rec.invstd.data_ptr(), rec.scale.data_ptr(), rec.shift.data_ptr(),
+                 bp.data_ptr(), s)
+            self._fused_stats["conv_up4_2"] = (bp, parts)
+        else:
+            call("uh_head_bwd", B, H, W, 64, oc, a.ptr, a.cstride, a.coff, fc.weight.data_ptr(), dl.data_ptr(),
+                 da.ptr, da.cstride, da.coff, hp.data_ptr(), s)
         hw = L.f32(oc * 65)
         call("uh_colsum_finalize", hp.data_ptr(), parts, oc * 65, 1, hw.data_ptr(), 0, s)
         hw = hw.view(oc, 65)
@@ -507,8 +524,18 @@ class UNetRun:
                 a2 = self.acts[f"conv{l + 1}_2"]
                 sg = skip_grads[l]
                 dsum = L.act(B, H, W, w)
-                call("uh_maxpool2_bwd", B, H, W, w, a2.ptr, a2.cstride, a2.coff, da.ptr, da.cstride, da.coff,
-                     sg.ptr, sg.cstride, sg.coff, dsum.ptr, dsum.cstride, dsum.coff, s)
+                if fuse_pool_stats():
+                    rec = self.recs[f"conv{l + 1}_2"]
+                    bparts = _lib.lib.uh_maxpool2_bwd_bnstat_parts(B, H, W, w)
+                    bp = L.f32(bparts * 2 * w)
+                    call("uh_maxpool2_bwd_bnstat", B, H, W, w, a2.ptr, a2.cstride, a2.coff, da.ptr, da.cstride,
+                         da.coff, sg.ptr, sg.cstride, sg.coff, dsum.ptr, dsum.cstride, dsum.coff, rec.y.ptr,
+                         rec.y.cstride, rec.y.coff, rec.mean.data_ptr(), rec.invstd.data_ptr(), rec.scale.data_ptr(),
+                         rec.shift.data_ptr(), bp.data_ptr(), s)
+                    self._fused_stats[f"conv{l + 1}_2"] = (bp, bparts)
+                else:
+                    call("uh_maxpool2_bwd", B, H, W, w, a2.ptr, a2.cstride, a2.coff, da.ptr, da.cstride, da.coff,
+                         sg.ptr, sg.cstride, sg.coff, dsum.ptr, dsum.cstride, dsum.coff, s)
                 da = dsum
             da = self._cbr_backward(f"conv{l + 1}_2", l, da, grads, stats_for=f"conv{l + 1}_1")
             da = self._cbr_backward(f"conv{l + 1}_1", l, da, grads, want_dgrad=(l > 0))
