@@ -169,6 +169,11 @@ int uh_bn_relu_bwd_apply(long long Mp, int C, const void* da, int da_cstride, in
 /* ---- MaxPool2d(2,2) (unet.py:103-124) ---------------------------------------------------- */
 int uh_maxpool2_fwd(int B, int H, int W, int C, const void* a, int a_cstride, int a_coff,
                     void* out, int o_cstride, int o_coff, uh_stream s);
+/* uh_bn_relu_apply followed by uh_maxpool2_fwd in one pass over y (the encoder's conv{l}_2 -> pool{l}, unet.py:100-124):
+ * a = relu(y*scale + shift) (pads zero) and p = MaxPool2d(2,2)(a).  C = 8 * a power of two. */
+int uh_bn_relu_apply_pool2(int B, int H, int W, int C, const void* y, int y_cstride, int y_coff,
+                           const float* scale, const float* shift,
+                           void* a, int a_cstride, int a_coff, void* p, int p_cstride, int p_coff, uh_stream s);
 /* da[m] = (dp routed to the FIRST maximum of the window, row-major order) + (add ? add[m] : 0) */
 int uh_maxpool2_bwd(int B, int H, int W, int C, const void* a, int a_cstride, int a_coff,
                     const void* dp, int dp_cstride, int dp_coff,

@@ -707,6 +707,27 @@ def test_maxpool_backward_with_batchnorm_backward_sums(B, H, W, C):
     assert ((got - want).abs() <= 1e-5 * mag.max() * 8 + 1e-6).all()
 
 
+@pytest.mark.parametrize("B,H,W,C", [(2, 8, 8, 64), (1, 4, 12, 128), (3, 2, 2, 512), (2, 64, 48, 64), (1, 6, 2, 256)])
+def test_batchnorm_relu_apply_with_pooling(B, H, W, C):
+    """uh_bn_relu_apply_pool2 writes what uh_bn_relu_apply followed by uh_maxpool2_fwd write, bit for bit, pads included."""
+    g = torch.Generator().manual_seed(71)
+    ya, st = _bn_bwd_setup(g, B, C, H, W)
+    mask = rowmask(B, H, W)
+    a0, a1 = new_act(B, H, W, 2 * C, DEV).window(0, C), new_act(B, H, W, 2 * C, DEV).window(0, C)
+    p0, p1 = new_act(B, H // 2, W // 2, C, DEV), new_act(B, H // 2, W // 2, C, DEV)
+    for t in (a1, p1):                                       # stale contents that have to be overwritten
+        t.padded_rows()[:, :] = 7.0
+    call("uh_bn_relu_apply", ya.Mp, C, ya.ptr, ya.cstride, ya.coff, st[2].data_ptr(), st[3].data_ptr(), mask.data_ptr(),
+         a0.ptr, a0.cstride, a0.coff, S())
+    call("uh_maxpool2_fwd", B, H, W, C, a0.ptr, a0.cstride, a0.coff, p0.ptr, p0.cstride, p0.coff, S())
+    call("uh_bn_relu_apply_pool2", B, H, W, C, ya.ptr, ya.cstride, ya.coff, st[2].data_ptr(), st[3].data_ptr(),
+         a1.ptr, a1.cstride, a1.coff, p1.ptr, p1.cstride, p1.coff, S())
+    torch.cuda.synchronize()
+    assert torch.equal(a0.padded_rows(), a1.padded_rows())
+    assert torch.equal(p0.buf, p1.buf)
+    pads_are_zero(p1)
+
+
 @pytest.mark.parametrize("B,H,W,C,OC", [(2, 8, 12, 64, 1), (1, 5, 7, 64, 2), (2, 16, 16, 8, 1)])
 def test_head_backward_with_batchnorm_backward_sums(B, H, W, C, OC):
     """uh_head_bwd_bnstat: gradient and weight partials as uh_head_bwd, bit for bit; sums as the separate pass."""

@@ -60,6 +60,7 @@ SIGNATURES = {
     "uh_head_fwd": (I, [I, I, I, I, I, P, I, I, P, P, P, P]),
     "uh_head_bwd_parts": (I, [I, I, I, I]),
     "uh_head_bwd_bnstat": (I, [I, I, I, I, I, P, I, I, P, P, P, I, I, P, P, I, I, P, P, P, P, P, P]),
+    "uh_bn_relu_apply_pool2": (I, [I, I, I, I, P, I, I, P, P, P, I, I, P, I, I, P]),
     "uh_maxpool2_bwd_bnstat_parts": (I, [I, I, I, I]),
     "uh_maxpool2_bwd_bnstat": (I, [I, I, I, I, P, I, I, P, I, I, P, I, I, P, I, I, P, I, I, P, P, P, P, P, P]),
     "uh_head_bwd": (I, [I, I, I, I, I, P, I, I, P, P, P, I, I, P, P]),

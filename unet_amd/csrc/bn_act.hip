@@ -383,6 +383,77 @@ extern "C" int uh_maxpool2_fwd(int B, int H, int W, int C, const void* a, int a_
   return uh_check_launch("maxpool2_fwd");
 }
 
+// a = relu(y*scale + shift) and p = MaxPool2d(2,2)(a) in one pass over y: one work item per 2x2 window and 8-channel
+// chunk, windows along the extra row and column included (they hold the pad positions of a, which get zeros).
+__global__ __launch_bounds__(256) void bn_relu_apply_pool_kernel(int B, int H, int W, int C, const char* __restrict__ y,
+                                                                 int y_cs, int y_co, const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift, char* __restrict__ a,
+                                                                 int a_cs, int a_co, char* __restrict__ p, int p_cs,
+                                                                 int p_co) {
+  const int oH = H / 2, oW = W / 2, oHp = oH + 1, oWp = oW + 1, Wp = W + 1, Hp = H + 1;
+  const int cpr = C / 8;
+  const long long total = (long long)B * oHp * oWp * cpr;
+  const int cc = threadIdx.x % cpr;             // 256 % cpr == 0 and the stride is a multiple of 256
+  float sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    sc[j] = scale[cc * 8 + j];
+    sh[j] = shift[cc * 8 + j];
+  }
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    long long r = i / cpr;
+    const int X = (int)(r % oWp);
+    r /= oWp;
+    const int Y = (int)(r % oHp);
+    const long long b = r / oHp;
+    const long long m00 = (b * Hp + 2 * Y) * Wp + 2 * X;
+    U4 o = {0u, 0u, 0u, 0u};
+    if (Y < oH && X < oW) {
+      const long long mm[4] = {m00, m00 + 1, m00 + Wp, m00 + Wp + 1};
+      U4 raw[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) raw[k] = *(const U4*)(y + (mm[k] * y_cs + y_co + cc * 8) * 2);
+      float best[8];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float f[8];
+        unpack8h(raw[k], f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          f[j] = fmaxf(f[j] * sc[j] + sh[j], 0.f);
+          best[j] = k ? fmaxf(best[j], f[j]) : f[j];
+        }
+        *(U4*)(a + (mm[k] * a_cs + a_co + cc * 8) * 2) = pack8(f);
+      }
+      o = pack8(best);                          // rounding to bf16 is monotonic: the maximum of the rounded values
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int yy = 2 * Y + (k >> 1), xx = 2 * X + (k & 1);
+        if (yy < Hp && xx < Wp) *(U4*)(a + (((b * Hp + yy) * Wp + xx) * a_cs + a_co + cc * 8) * 2) = o;
+      }
+    }
+    *(U4*)(p + (((b * oHp + Y) * oWp + X) * p_cs + p_co + cc * 8) * 2) = o;
+  }
+}
+
+extern "C" int uh_bn_relu_apply_pool2(int B, int H, int W, int C, const void* y, int y_cstride, int y_coff,
+                                      const float* scale, const float* shift, void* a, int a_cstride, int a_coff,
+                                      void* p, int p_cstride, int p_coff, uh_stream s) {
+  UH_REQUIRE(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "bn_relu_apply_pool2: H=%d W=%d must be even", H, W);
+  UH_REQUIRE(C > 0 && C % 8 == 0 && 256 % (C / 8) == 0, "bn_relu_apply_pool2: C=%d must be 8 times a power of two <= 2048", C);
+  UH_REQUIRE(y && scale && shift && a && p, "bn_relu_apply_pool2: null pointer");
+  UH_REQUIRE(y_cstride % 8 == 0 && y_coff % 8 == 0 && a_cstride % 8 == 0 && a_coff % 8 == 0 && p_cstride % 8 == 0 &&
+                 p_coff % 8 == 0, "bn_relu_apply_pool2: bad views");
+  const long long total = uh_mp(B, H / 2, W / 2) * (C / 8);
+  long long blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(bn_relu_apply_pool_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, B, H, W, C,
+                     (const char*)y, y_cstride, y_coff, scale, shift, (char*)a, a_cstride, a_coff, (char*)p, p_cstride,
+                     p_coff);
+  return uh_check_launch("bn_relu_apply_pool2");
+}
+
 // STATS: `da` is the gradient at the output of a conv + BatchNorm + ReLU layer (conv{l}_2, whose activation `a` was
 // pooled): the layer's BatchNorm-backward sums (what bn_relu_bwd_reduce_kernel computes from da and the layer's fp16
 // conv output y in a pass of its own) are taken here, from the values as they are stored (after rounding to bf16).

@@ -36,6 +36,12 @@ def fuse_bn_bwd():
 def fuse_pool_stats():
     return os.environ.get("UNET_AMD_FUSE_POOL_STATS", "1") == "1"
 
+
+# UNET_AMD_FUSE_POOL_FWD=0: train-mode MaxPool2d is a pass of its own (uh_maxpool2_fwd) after uh_bn_relu_apply instead of
+# being written by the pass that applies BatchNorm + ReLU to conv{l}_2 (uh_bn_relu_apply_pool2).
+def fuse_pool_fwd():
+    return os.environ.get("UNET_AMD_FUSE_POOL_FWD", "1") == "1"
+
 _SIDE_STREAMS = {}
 
 
@@ -185,8 +191,9 @@ class UNetRun:
         f = self.lease.f32(4 * C)
         return f[0:C], f[C:2 * C], f[2 * C:3 * C], f[3 * C:4 * C]     # mean, invstd, scale, shift
 
-    def _finish_bn(self, rec, lvl, stat, parts, conv, bn):
-        """statistics -> scale/shift (+ running stats), then a_out = relu(y*scale+shift)."""
+    def _finish_bn(self, rec, lvl, stat, parts, conv, bn, pooled=None):
+        """statistics -> scale/shift (+ running stats), then a_out = relu(y*scale+shift); pooled = MaxPool2d(2,2) of
+        a_out in the same pass when given."""
         B, H, W = self.geo[lvl]
         C = rec.cout
         rec.mean, rec.invstd, rec.scale, rec.shift = self._bn_params(C)
@@ -195,15 +202,20 @@ class UNetRun:
              rec.shift.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
              bn.num_batches_tracked.data_ptr(), _stream())
         y, a = rec.y, rec.a_out
+        if pooled is not None:
+            call("uh_bn_relu_apply_pool2", B, H, W, C, y.ptr, y.cstride, y.coff, rec.scale.data_ptr(),
+                 rec.shift.data_ptr(), a.ptr, a.cstride, a.coff, pooled.ptr, pooled.cstride, pooled.coff, _stream())
+            return
         call("uh_bn_relu_apply", y.Mp, C, y.ptr, y.cstride, y.coff, rec.scale.data_ptr(), rec.shift.data_ptr(),
              self.masks[lvl].data_ptr(), a.ptr, a.cstride, a.coff, _stream())
 
-    def _cbr(self, name, a_in, lvl, a_out):
-        """conv3x3 + BN + ReLU (unet.py:99 etc.).  a_in is None for the first layer (reads self.x)."""
+    def _cbr(self, name, a_in, lvl, a_out, pooled=None):
+        """conv3x3 + BN + ReLU (unet.py:99 etc.).  a_in is None for the first layer (reads self.x).  pooled: where the
+        2x2 max pooling of the output goes (train mode: written by the pass that writes a_out); returns True if done."""
         with layer_range("fwd/" + name):
-            return self._cbr_launch(name, a_in, lvl, a_out)
+            return self._cbr_launch(name, a_in, lvl, a_out, pooled)
 
-    def _cbr_launch(self, name, a_in, lvl, a_out):
+    def _cbr_launch(self, name, a_in, lvl, a_out, pooled=None):
         conv = getattr(self.m, name)
         bn = getattr(self.m, name.replace("conv", "bn", 1))
         B, H, W = self.geo[lvl]
@@ -230,8 +242,9 @@ class UNetRun:
                 self._gemm(B, H, W, a_in.ptr, a_in.cstride, a_in.coff, cin, wp.data_ptr(), cout, 9,
                      EPI_RAW_STATS, rec.y.ptr, rec.y.cstride, rec.y.coff, conv.bias.data_ptr(), None, None,
                      stat.data_ptr(), self.masks[lvl].data_ptr(), s)
-            self._finish_bn(rec, lvl, stat, parts, conv, bn)
+            self._finish_bn(rec, lvl, stat, parts, conv, bn, pooled)
             self.recs[name] = rec
+            return pooled is not None
         else:
             f = self.lease.f32(2 * cout)
             scale, shift = f[:cout], f[cout:]
@@ -246,7 +259,7 @@ class UNetRun:
                 self._gemm(B, H, W, a_in.ptr, a_in.cstride, a_in.coff, cin, wp.data_ptr(), cout, 9,
                      EPI_AFFINE_RELU, a_out.ptr, a_out.cstride, a_out.coff, None, scale.data_ptr(),
                      shift.data_ptr(), None, self.masks[lvl].data_ptr(), s)
-        return a_out
+        return False
 
     # ------------------------------------------------------------------ forward
     def forward(self):
@@ -263,11 +276,12 @@ class UNetRun:
             a1 = L.act(B, H, W, w)
             self._cbr(f"conv{l + 1}_1", cur, l, a1)
             a2 = cat[l].window(0, w) if l < 4 else L.act(B, H, W, w)
-            self._cbr(f"conv{l + 1}_2", a1, l, a2)
+            p = L.act(B, H // 2, W // 2, w) if l < 4 else None
+            pooled = self._cbr(f"conv{l + 1}_2", a1, l, a2, p if fuse_pool_fwd() else None)
             acts[f"conv{l + 1}_1"], acts[f"conv{l + 1}_2"] = a1, a2
             if l < 4:
-                p = L.act(B, H // 2, W // 2, w)
-                call("uh_maxpool2_fwd", B, H, W, w, a2.ptr, a2.cstride, a2.coff, p.ptr, p.cstride, p.coff, s)
+                if not pooled:
+                    call("uh_maxpool2_fwd", B, H, W, w, a2.ptr, a2.cstride, a2.coff, p.ptr, p.cstride, p.coff, s)
                 acts[f"pool{l + 1}"] = p
                 cur = p
             else:
