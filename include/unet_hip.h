@@ -266,6 +266,16 @@ int uh_add(long long Mp, int C, const void* a, int a_cstride, int a_coff, const 
 /* weight gradient of the depthwise convolution: the partial[parts][9][C] rows of uh_dwconv3x3_wgrad summed into the
  * module's own layout out[c_real][1][3][3] (lunext.py:14), padding channels dropped */
 int uh_dw_wgrad_finalize(const float* partial, int parts, int C, int c_real, float* out, uh_stream s);
+/* The backward of one DepthwiseConvBlock (lunext.py:6-30) behind its BatchNorm sums, in one pass: what
+ * uh_bn_res_relu_bwd_apply + uh_dwconv3x3_dgrad + uh_dwconv3x3_wgrad compute, without storing dy and dr
+ * (dy is used in fp32, not rounded to bf16).  coef is uh_bn_bwd_finalize's output; partial[parts][9][C] goes to
+ * uh_dw_wgrad_finalize.  C a power of two in [8, 512]. */
+int uh_dwblock_bwd_parts(int B, int H, int W, int C);
+int uh_dwblock_bwd(int B, int H, int W, int C, const void* da, int da_cstride, int da_coff,
+                   const void* y, int y_cstride, int y_coff, const void* x, int x_cstride, int x_coff,
+                   const float* w, int c_real,
+                   const float* mean, const float* invstd, const float* scale, const float* shift, const float* coef,
+                   void* dx, int dx_cstride, int dx_coff, float* partial, uh_stream s);
 /* fully fused gate for the 8-channel top level; wts = W1[8][8]|W2[8][8]|W3[8][8]|b1[8]|b2[8]|b3[8] fp32
  * ([co][ci], zero beyond the c_real real channels; only those are computed),
  * partial[blk][216] (blk < uh_gate8_parts) holds the weight gradients in the same layout */

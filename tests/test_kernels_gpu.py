@@ -728,6 +728,61 @@ def test_batchnorm_relu_apply_with_pooling(B, H, W, C):
     pads_are_zero(p1)
 
 
+@pytest.mark.parametrize("B,H,W,C,c_real", [(2, 16, 16, 64, 64), (1, 20, 12, 8, 3), (2, 5, 7, 128, 128), (1, 33, 4, 256, 256),
+                                            (1, 3, 3, 512, 512)])
+def test_depthwise_block_backward_in_one_pass(B, H, W, C, c_real):
+    """uh_dwblock_bwd against the three passes it replaces (uh_bn_res_relu_bwd_apply, uh_dwconv3x3_dgrad,
+    uh_dwconv3x3_wgrad): the same gradients up to the bf16 rounding of dy that the fused pass does not make."""
+    g = torch.Generator().manual_seed(73)
+    live = (torch.arange(C) < c_real).float().view(1, C, 1, 1)
+    x = bf(torch.randn(B, C, H, W, generator=g)) * live
+    da = bf(torch.randn(B, C, H, W, generator=g)) * live
+    y = (torch.randn(B, C, H, W, generator=g) * 1.5 + 0.2).half().float() * live
+    wt = (torch.randn(c_real, 1, 3, 3, generator=g) / 3).to(DEV)
+    mean, invstd = torch.randn(C, generator=g) * 0.2, torch.rand(C, generator=g) + 0.5
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g) * 0.3
+    scale = gamma * invstd
+    st = [(t * live.view(-1) if i >= 2 else t).to(DEV) for i, t in enumerate((mean, invstd, scale, beta - mean * scale))]
+    coef = (torch.randn(2, C, generator=g) * 0.05).to(DEV)
+    xa, daa, ya = act_from(x, cstride=2 * C, coff=C), act_from(da), act_from(y, half=True)
+    mask = rowmask(B, H, W)
+    stp = [t.data_ptr() for t in st]
+    dy, dr, dx0, dx1 = (new_act(B, H, W, C, DEV) for _ in range(4))
+    call("uh_bn_res_relu_bwd_apply", xa.Mp, C, daa.ptr, daa.cstride, daa.coff, ya.ptr, ya.cstride, ya.coff, xa.ptr,
+         xa.cstride, xa.coff, *stp, coef.data_ptr(), mask.data_ptr(), dy.ptr, dy.cstride, dy.coff, dr.ptr, dr.cstride,
+         dr.coff, S())
+    call("uh_dwconv3x3_dgrad", B, H, W, C, dy.ptr, dy.cstride, dy.coff, wt.data_ptr(), c_real, dr.ptr, dr.cstride,
+         dr.coff, mask.data_ptr(), dx0.ptr, dx0.cstride, dx0.coff, S())
+    p0 = lib.uh_dw_parts(B, H, W, C)
+    wp0 = torch.empty(p0, 9, C, device=DEV)
+    call("uh_dwconv3x3_wgrad", B, H, W, C, dy.ptr, dy.cstride, dy.coff, xa.ptr, xa.cstride, xa.coff, wp0.data_ptr(), S())
+    p1 = lib.uh_dwblock_bwd_parts(B, H, W, C)
+    assert p1 >= 1
+    wp1 = torch.full((p1, 9, C), float("nan"), device=DEV)
+    dx1.padded_rows()[:, :] = 5.0
+    call("uh_dwblock_bwd", B, H, W, C, daa.ptr, daa.cstride, daa.coff, ya.ptr, ya.cstride, ya.coff, xa.ptr, xa.cstride,
+         xa.coff, wt.data_ptr(), c_real, *stp, coef.data_ptr(), dx1.ptr, dx1.cstride, dx1.coff,
+         wp1.data_ptr(), S())
+    dw0, dw1 = torch.empty(c_real, 1, 3, 3, device=DEV), torch.empty(c_real, 1, 3, 3, device=DEV)
+    call("uh_dw_wgrad_finalize", wp0.data_ptr(), p0, C, c_real, dw0.data_ptr(), S())
+    call("uh_dw_wgrad_finalize", wp1.data_ptr(), p1, C, c_real, dw1.data_ptr(), S())
+    torch.cuda.synchronize()
+    pads_are_zero(dx1)
+    close(dx1.to_nchw(), dx0.to_nchw(), 1.2e-2, "dx")           # nine products of values rounded at 2^-9, then summed
+    assert torch.isfinite(dw1).all()
+    scale_dw = (dy.to_nchw().abs().flatten(2).sum(2).sum(0)[:c_real] * x.abs().max()).cpu().view(-1, 1, 1, 1)
+    assert ((dw1 - dw0).abs().cpu() <= 4e-3 * scale_dw + 1e-5).all(), "dw"
+    # and against fp32 autograd of the same block
+    xr, wr = x.clone().requires_grad_(True), wt.cpu().clone().requires_grad_(True)
+    c = lambda v: v.view(1, -1, 1, 1)                                            # noqa: E731
+    d = da * ((y * c(st[2].cpu()) + c(st[3].cpu()) + x) > 0)
+    dyr = c(st[2].cpu()) * (d - c(coef[0].cpu()) - (y - c(mean)) * c(invstd) * c(coef[1].cpu())) * live
+    out = F.conv2d(xr, torch.cat([wr, torch.zeros(C - c_real, 1, 3, 3)]), padding=1, groups=C)
+    out.backward(dyr)
+    close(dx1.to_nchw(), xr.grad + d, 1e-2, "dx against autograd")
+    close(dw1, wr.grad, 2e-3, "dw against autograd")
+
+
 @pytest.mark.parametrize("B,H,W,C,OC", [(2, 8, 12, 64, 1), (1, 5, 7, 64, 2), (2, 16, 16, 8, 1)])
 def test_head_backward_with_batchnorm_backward_sums(B, H, W, C, OC):
     """uh_head_bwd_bnstat: gradient and weight partials as uh_head_bwd, bit for bit; sums as the separate pass."""

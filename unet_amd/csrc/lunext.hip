@@ -479,6 +479,232 @@ extern "C" int uh_dwconv3x3_wgrad(int B, int H, int W, int C, const void* dy, in
   return uh_check_launch("dwconv3x3_wgrad");
 }
 
+// ---- the whole backward of relu(BN(dwconv3x3(x)) + x) behind the BatchNorm sums, in one pass --------------------------
+//   d     = da * (y*scale + shift + x > 0)            gradient at the sum = gradient of the residual branch
+//   dy    = scale*(d - coef0 - xhat*coef1)            gradient of the depthwise conv output, 0 on pad positions
+//   dx[m] = sum_t dy[m - off(t)]*w[t] + d[m]
+//   dw[t] = sum_m dy[m - off(t)]*x[m]                 (= sum_m dy[m]*x[m + off(t)])
+// Both sums run over the same mirrored 3x3 window of dy around m, which is never stored: a thread owns one position
+// and FOUR channels (8-byte accesses: the window, the filters and the nine weight-gradient sums of eight channels
+// would not fit the register file at a useful occupancy) and walks down a strip as the kernels above do, evaluating
+// dy for the three positions of each new bottom row from da, y and x (neighbouring threads evaluate the same
+// elements again; the loads hit in L1).  dy = scale*d - (y*cc + bp) with cc = scale*coef1*invstd,
+// bp = scale*coef0 - cc*mean.
+typedef uint2 U2;
+__device__ __forceinline__ void unpack4(const U2& u, float (&f)[4]) {
+  f[0] = __uint_as_float(u.x << 16);
+  f[1] = __uint_as_float(u.x & 0xffff0000u);
+  f[2] = __uint_as_float(u.y << 16);
+  f[3] = __uint_as_float(u.y & 0xffff0000u);
+}
+__device__ __forceinline__ void unpack4h(const U2& u, float (&f)[4]) {
+  typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+  const h2 a = *reinterpret_cast<const h2*>(&u.x), b = *reinterpret_cast<const h2*>(&u.y);
+  f[0] = (float)a[0];
+  f[1] = (float)a[1];
+  f[2] = (float)b[0];
+  f[3] = (float)b[1];
+}
+static inline dim3 dwb_grid(int B, int H, int W, int C) {
+  const int xt = 256 / (C / 4);
+  const long long strips = ((long long)B * (H + 1) + DW_R - 1) / DW_R;
+  return dim3((unsigned)((strips * (W + 1) + xt - 1) / xt));
+}
+
+struct DwbRaw {
+  U2 g, v, r;
+};
+
+__global__ __launch_bounds__(256) void dwblock_bwd_kernel(
+    long long Mp, int C, int Wp, int Hp, const char* __restrict__ da, int da_cs, int da_co, const char* __restrict__ y,
+    int y_cs, int y_co, const char* __restrict__ x, int x_cs, int x_co, const float* __restrict__ wt, int c_real,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ coef, char* __restrict__ dx, int dx_cs, int dx_co,
+    float* __restrict__ partial) {
+  extern __shared__ float lds[];
+  const int cpr = C / 4, xt = 256 / cpr;           // cpr a power of two <= 128: at least two positions per workgroup
+  const int cc = threadIdx.x % cpr, xi = threadIdx.x / cpr;
+  const int c0 = cc * 4;
+  const long long rows = Mp / Wp;
+  const long long q = (long long)blockIdx.x * xt + xi;
+  const long long strip = q / Wp;
+  const int x0 = (int)(q - strip * Wp);
+  const long long r0 = strip * DW_R;
+  const long long left = rows - r0;
+  const int nr = left > 0 ? (int)(left < DW_R ? left : DW_R) : 0;
+  // Every thread of the workgroup walks all DW_R rows (the row exchange below has a barrier per row).  Row e of the
+  // walk is tensor row r0 - 1 + e (e = 0: the row above the strip ... DW_R + 1: the row below it); rows e <= lim exist,
+  // later ones count as padding and are fetched from the last row that does (a thread past the end of the tensor:
+  // position 0, nothing exists).
+  const long long m0 = nr > 0 ? r0 * Wp + x0 : 0;
+  const int lim = nr > 0 ? (int)(left < DW_R + 1 ? left : DW_R + 1) : -1;
+  const bool edge_l = xi == 0, edge_r = xi == xt - 1, edge = edge_l || edge_r;
+  const int hoff = edge_l ? -1 : 1;                // the column an edge thread evaluates for its missing neighbour
+  const bool col_own = x0 < Wp - 1, col_halo = x0 + hoff >= 0 && x0 + hoff < Wp - 1;
+  int ry = (int)((r0 + Hp - 1) % Hp);              // image row of walk row 0 (the row above tensor row 0 counts as padding)
+  float acc[9][4], w[9][4], sc[4], sh[4], bp[4], cq[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = c0 + j;
+    sc[j] = scale[c];
+    sh[j] = shift[c];
+    cq[j] = sc[j] * coef[C + c] * invstd[c];
+    bp[j] = sc[j] * coef[c] - cq[j] * mean[c];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      acc[t][j] = 0.f;
+      w[t][j] = (c < c_real) ? wt[c * 9 + t] : 0.f;
+    }
+  }
+  const long long da_row = (long long)da_cs * 2 * Wp, y_row = (long long)y_cs * 2 * Wp, x_row = (long long)x_cs * 2 * Wp;
+  const char* dap = da + ((m0 - Wp) * da_cs + da_co + c0) * 2;      // walk row 0; guard rows make it readable
+  const char* yp = y + ((m0 - Wp) * y_cs + y_co + c0) * 2;
+  const char* xp = x + ((m0 - Wp) * x_cs + x_co + c0) * 2;
+  const long long da_h = (long long)hoff * da_cs * 2, y_h = (long long)hoff * y_cs * 2, x_h = (long long)hoff * x_cs * 2;
+  int e_next = 0;                                    // the walk row the pointers are at
+  auto fetch = [&](DwbRaw& own, DwbRaw& hal, bool& ok) {
+    own.g = *(const U2*)dap;
+    own.v = *(const U2*)yp;
+    own.r = *(const U2*)xp;
+    if (edge) {
+      hal.g = *(const U2*)(dap + da_h);
+      hal.v = *(const U2*)(yp + y_h);
+      hal.r = *(const U2*)(xp + x_h);
+    }
+    ok = e_next <= lim && ry != Hp - 1;
+    const bool step = e_next <= nr;                  // the row after this one can be read as well
+    dap += step ? da_row : 0;
+    yp += step ? y_row : 0;
+    xp += step ? x_row : 0;
+    ++e_next;
+    ry = ry + 1 == Hp ? 0 : ry + 1;
+  };
+  auto eval = [&](const DwbRaw& t, bool keep, float (&dyv)[4], float (&dc)[4], float (&xc)[4]) {
+    float gf[4], vf[4], xf[4];
+    unpack4(t.g, gf);
+    unpack4h(t.v, vf);
+    unpack4(t.r, xf);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float d = (keep && vf[j] * sc[j] + sh[j] + xf[j] > 0.f) ? gf[j] : 0.f;
+      dc[j] = d;
+      xc[j] = keep ? xf[j] : 0.f;
+      dyv[j] = keep ? fmaf(sc[j], d, -fmaf(vf[j], cq[j], bp[j])) : 0.f;
+    }
+  };
+  // dy of this thread's column goes to slot xi + 1 of the row buffer, the edge threads' extra column to slot 0 / xt + 1;
+  // after the barrier the neighbours' values are read back.  Two buffers alternate, so one barrier per row is enough.
+  float win[3][3][4], dcen[3][4], xcen[3][4];       // [row slot][column][channel]
+  auto exchange = [&](int e, const DwbRaw& own, const DwbRaw& hal, bool ok, float (&dst)[3][4], float (&dc)[4],
+                      float (&xc)[4]) {
+    float* buf = lds + (e & 1) * (xt + 2) * C + c0;
+    eval(own, ok && col_own, dst[1], dc, xc);
+    *(f32x4*)(buf + (xi + 1) * C) = f32x4{dst[1][0], dst[1][1], dst[1][2], dst[1][3]};
+    if (edge) {
+      float hv[4], t0[4], t1[4];
+      eval(hal, ok && col_halo, hv, t0, t1);
+      *(f32x4*)(buf + (edge_l ? 0 : xt + 1) * C) = f32x4{hv[0], hv[1], hv[2], hv[3]};
+    }
+    __syncthreads();
+    const f32x4 l = *(const f32x4*)(buf + xi * C), r = *(const f32x4*)(buf + (xi + 2) * C);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      dst[0][j] = l[j];
+      dst[2][j] = r[j];
+    }
+  };
+  DwbRaw own, hal = {{0u, 0u}, {0u, 0u}, {0u, 0u}}, own_n, hal_n = hal;
+  bool ok, ok_n;
+  fetch(own, hal, ok);
+  fetch(own_n, hal_n, ok_n);
+  exchange(0, own, hal, ok, win[0], dcen[0], xcen[0]);
+  own = own_n; hal = hal_n; ok = ok_n;
+  fetch(own_n, hal_n, ok_n);
+  exchange(1, own, hal, ok, win[1], dcen[1], xcen[1]);
+  bool okc[3] = {false, ok && col_own, false};      // is the centre of the row in slot k a real position
+  char* op = dx + (m0 * dx_cs + dx_co + c0) * 2;
+  const long long orow = (long long)dx_cs * 2 * Wp;
+#pragma unroll
+  for (int r = 0; r < DW_R; ++r) {
+    float(&top)[3][4] = win[r % 3];
+    float(&mid)[3][4] = win[(r + 1) % 3];
+    float(&bot)[3][4] = win[(r + 2) % 3];
+    own = own_n; hal = hal_n; ok = ok_n;
+    if (r + 1 < DW_R) fetch(own_n, hal_n, ok_n);    // the row after the next one is in flight while this one is used
+    exchange(r + 2, own, hal, ok, bot, dcen[(r + 2) % 3], xcen[(r + 2) % 3]);
+    okc[(r + 2) % 3] = ok && col_own;
+    const float(&dm)[4] = dcen[(r + 1) % 3];
+    const float(&xm)[4] = xcen[(r + 1) % 3];         // 0 where the centre is padding or does not exist
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v = dm[j];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        v = fmaf(bot[2 - d][j], w[d][j], v);
+        acc[d][j] = fmaf(xm[j], bot[2 - d][j], acc[d][j]);
+      }
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        v = fmaf(mid[2 - d][j], w[3 + d][j], v);
+        acc[3 + d][j] = fmaf(xm[j], mid[2 - d][j], acc[3 + d][j]);
+      }
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        v = fmaf(top[2 - d][j], w[6 + d][j], v);
+        acc[6 + d][j] = fmaf(xm[j], top[2 - d][j], acc[6 + d][j]);
+      }
+      o[j] = okc[(r + 1) % 3] ? v : 0.f;             // (the window around a pad position holds real neighbours)
+    }
+    if (r < nr) {
+      U2 ov;
+      ov.x = pack2(o[0], o[1]);
+      ov.y = pack2(o[2], o[3]);
+      *(U2*)op = ov;
+      op += orow;
+    }
+  }
+  // lds[xi][9][C] -> partial[blk][9][C]
+  __syncthreads();
+  float* mine = lds + ((long long)xi * 9) * C + c0;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) mine[t * C + j] = acc[t][j];
+  __syncthreads();
+  float* row = partial + (long long)blockIdx.x * 9 * C;
+  for (int i = threadIdx.x; i < 9 * C; i += 256) {
+    float v = 0.f;
+    for (int k = 0; k < xt; ++k) v += lds[(long long)k * 9 * C + i];
+    row[i] = v;
+  }
+}
+
+extern "C" int uh_dwblock_bwd_parts(int B, int H, int W, int C) {
+  if (!(B > 0 && H > 0 && W > 0 && C >= 8 && C <= 512 && (C & (C - 1)) == 0)) return 0;
+  return (int)dwb_grid(B, H, W, C).x;
+}
+
+extern "C" int uh_dwblock_bwd(int B, int H, int W, int C, const void* da, int da_cstride, int da_coff, const void* y,
+                              int y_cstride, int y_coff, const void* x, int x_cstride, int x_coff, const float* w,
+                              int c_real, const float* mean, const float* invstd, const float* scale,
+                              const float* shift, const float* coef, void* dx, int dx_cstride, int dx_coff,
+                              float* partial, uh_stream s) {
+  UH_REQUIRE(B > 0 && H > 0 && W > 0 && da && y && x && w && mean && invstd && scale && shift && coef && dx && partial,
+             "dwblock_bwd: bad arguments");
+  UH_REQUIRE(C >= 8 && C <= 512 && (C & (C - 1)) == 0, "dwblock_bwd: C=%d must be a power of two in [8,512]", C);
+  UH_REQUIRE(c_real > 0 && c_real <= C, "dwblock_bwd: c_real=%d of C=%d", c_real, C);
+  UH_REQUIRE(da_cstride % 4 == 0 && da_coff % 4 == 0 && y_cstride % 4 == 0 && y_coff % 4 == 0 && x_cstride % 4 == 0 &&
+                 x_coff % 4 == 0 && dx_cstride % 4 == 0 && dx_coff % 4 == 0, "dwblock_bwd: bad views");
+  const long long Mp = uh_mp(B, H, W);
+  const int xt = 256 / (C / 4);
+  hipLaunchKernelGGL(dwblock_bwd_kernel, dwb_grid(B, H, W, C), dim3(256), (size_t)xt * 9 * C * 4, (hipStream_t)s, Mp, C,
+                     W + 1, H + 1, (const char*)da, da_cstride, da_coff, (const char*)y, y_cstride, y_coff,
+                     (const char*)x, x_cstride, x_coff, w, c_real, mean, invstd, scale, shift, coef, (char*)dx,
+                     dx_cstride, dx_coff, partial);
+  return uh_check_launch("dwblock_bwd");
+}
+
 // partial[P][9][C] -> the module's own weight-gradient layout out[c_real][1][3][3] (padding channels dropped)
 __global__ __launch_bounds__(1024) void dw_wgrad_finalize_kernel(const float* __restrict__ partial, int P, int C,
                                                                  int c_real, float* __restrict__ out) {

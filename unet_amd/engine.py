@@ -25,8 +25,10 @@ WIDTHS = (64, 128, 256, 512, 1024)
 # default: measured on the training step (batch 32, 256^2) the nine passes it saves and the longer epilogue cancel
 # (14.03 against 14.06 ms; the 3x3 kernel drops from 904 to 853 TFLOP/s in the step) -- the epilogue waits for the
 # layer's fp16 conv output, and loads that return in order cannot stay in flight across the main loop's staging waits.
-def fuse_bn_bwd():
-    return os.environ.get("UNET_AMD_FUSE_BN_BWD", "0") == "1"
+def fuse_bn_bwd(lvl=0):
+    if os.environ.get("UNET_AMD_FUSE_BN_BWD", "0") == "1":
+        return True
+    return str(lvl) in os.environ.get("UNET_AMD_FUSE_BN_BWD_LEVELS", "")
 
 
 
@@ -398,7 +400,7 @@ class UNetRun:
             # start late undo the even split anyway (step 14.31 -> 14.12 ms).  Alone on the chip even cuts win, but
             # the choice does not follow the stream setting: both settings then give bit-identical results.
             prev = self.recs.get(stats_for) if stats_for else None
-            if prev is not None and fuse_bn_bwd() and prev.cout == cin:
+            if prev is not None and fuse_bn_bwd(lvl) and prev.cout == cin:
                 # `out` is the gradient at the output of layer `stats_for` (conv + BatchNorm + ReLU): its
                 # BatchNorm-backward sums are taken while the tiles are still in the accumulators
                 parts = _lib.lib.uh_conv_gemm_mtiles(B, H, W, cin)

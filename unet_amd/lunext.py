@@ -24,6 +24,10 @@ from .packing import lunext_packer_for
 
 L = _lib.lib
 
+# UNET_AMD_LUNEXT_FUSED_DW=0: the backward of a DepthwiseConvBlock behind its BatchNorm sums runs as three passes
+# (uh_bn_res_relu_bwd_apply, uh_dwconv3x3_dgrad, uh_dwconv3x3_wgrad) instead of one (uh_dwblock_bwd).
+FUSED_DW_BWD = os.environ.get("UNET_AMD_LUNEXT_FUSED_DW", "1") == "1"
+
 
 def _padc(c):
     return max(8, (c + 7) // 8 * 8)
@@ -136,6 +140,19 @@ class LUNeXtRun:
         call("uh_bn_bwd_finalize", partial.data_ptr(), parts, Cp, C, B * H * W, dgb[0].data_ptr(), dgb[1].data_ptr(),
              coef.data_ptr(), 0, s)
         grads[name + ".bn.weight"], grads[name + ".bn.bias"] = dgb[0], dgb[1]
+        if FUSED_DW_BWD:
+            wparts = L.uh_dwblock_bwd_parts(B, H, W, Cp)
+            wp = Ls.f32(wparts * 9 * Cp)
+            dx = Ls.act(B, H, W, Cp)
+            dw = torch.empty(C, 1, 3, 3, dtype=torch.float32, device=self.device)
+            call("uh_dwblock_bwd", B, H, W, Cp, da.ptr, da.cstride, da.coff, y.ptr, y.cstride, y.coff, x.ptr,
+                 x.cstride, x.coff, rec.wt.data_ptr(), C, *st, coef.data_ptr(), dx.ptr, dx.cstride,
+                 dx.coff, wp.data_ptr(), s)
+            with self._side() as s2:
+                call("uh_dw_wgrad_finalize", wp.data_ptr(), wparts, Cp, C, dw.data_ptr(), s2)
+            grads[name + ".depthwise.weight"] = dw
+            grads[name + ".depthwise.bias"] = self._zeros(C)
+            return dx
         dy, dr = Ls.act(B, H, W, Cp), Ls.act(B, H, W, Cp)
         call("uh_bn_res_relu_bwd_apply", x.Mp, Cp, da.ptr, da.cstride, da.coff, y.ptr, y.cstride, y.coff, x.ptr,
              x.cstride, x.coff, *st, coef.data_ptr(), mask.data_ptr(), dy.ptr, dy.cstride, dy.coff, dr.ptr, dr.cstride,
