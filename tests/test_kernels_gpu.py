@@ -225,7 +225,11 @@ def test_conv_transpose_fwd(B, h, w, Cin, Cout):
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 16, 16, 64, 64), (1, 8, 24, 128, 64), (3, 4, 4, 64, 128),
-                                            (2, 2, 2, 128, 128), (1, 40, 40, 64, 64)])
+                                            (2, 2, 2, 128, 128), (1, 40, 40, 64, 64),
+                                            # widths that are multiples of 64 walk down column strips
+                                            (1, 6, 128, 64, 64), (2, 3, 256, 128, 64), (3, 5, 128, 64, 128),
+                                            (2, 40, 256, 64, 64), (2, 10, 64, 64, 64), (1, 1, 64, 64, 64),
+                                            (5, 64, 64, 128, 128)])
 def test_conv_wgrad(B, H, W, Cin, Cout):
     g = torch.Generator().manual_seed(31)
     x = bf(torch.randn(B, Cin, H, W, generator=g))

@@ -2,7 +2,9 @@
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-firsts = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("void conv_first_fwd_kernel")]
+import os
+MARK = os.environ.get("TIMELINE_FIRST_KERNEL", "void conv_first_fwd_kernel")      # the first launch of a step
+firsts = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith(MARK)]
 k = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 a, b = firsts[-k], firsts[-k + 1]
 step = rows[a:b]

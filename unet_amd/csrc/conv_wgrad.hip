@@ -13,6 +13,7 @@
 // k slice: 4 (n) x T accumulator tiles.  Partial results of the pixel splits are written to a
 // workspace slab and summed by uh_wgrad_reduce (deterministic, no atomics).
 #include "common.h"
+#include <cstdlib>
 
 struct WgradArgs {
   const char* dY;
@@ -24,6 +25,9 @@ struct WgradArgs {
   int N, K, Wp;
   int S;        // pixel splits
   int remap;    // 1: 1-D grid, every split's tiles on one XCD (see the kernel)
+  // conv_wgrad_col_kernel only: rows_per_split counts stages, a stage index i is (strip i / total_rows, row i % total_rows)
+  int total_rows;   // B * (H + 1)
+  int nstrip;       // W / 64
 };
 
 template <int T>
@@ -154,11 +158,175 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs p) {
       }
 }
 
+// ---- T = 9, W a multiple of 64: column walk with a rotating band ring and one stage of prefetch ------------------------
+// A split walks DOWN a 64-pixel-wide column strip, one image row per stage (the pad column, whose dY is zero, is
+// never visited).  The A bands of filter rows 0, 1, 2 of a stage are then the bands of rows 1, 2 of the previous stage
+// and ONE new band: four LDS slots rotate, three in use and one being filled, and dY has two buffers, so the loads of
+// stage i+1 (8 KB of dY + 9 KB of A instead of 16 + 51 per 128 pixels) are in flight while stage i is consumed.  One
+// barrier per stage: behind it every wave has finished reading stage i and all of stage i+1 has landed.
+// A stage index i is (strip i / total_rows, row i % total_rows); where a split passes from one strip to the next the
+// three bands are fetched afresh, without prefetch.
+struct WColCfg {
+  static constexpr int DY_BYTES = 64 * 128;        // one dY buffer: 64 pixels x 64 channels
+  static constexpr int BAND_GROUPS = 9;            // 72 >= 66 rows
+  static constexpr int BAND_BYTES = BAND_GROUPS * 1024;
+  static constexpr int BAND_OFF = 2 * DY_BYTES;
+  static constexpr int LDS_BYTES = BAND_OFF + 4 * BAND_BYTES;
+};
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad_col_kernel(WgradArgs p) {
+  using C = WColCfg;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int n0, k0, split;                 // as in conv_wgrad_kernel
+  if (p.remap) {
+    const int tn = p.N / 64, tiles = tn * (p.K / 64);
+    const int q = blockIdx.x >> 3;
+    split = (blockIdx.x & 7) + 8 * (q / tiles);
+    if (split >= p.S) return;
+    const int t = q % tiles;
+    n0 = (t % tn) * 64;
+    k0 = (t / tn) * 64;
+  } else {
+    n0 = blockIdx.x * 64;
+    k0 = blockIdx.y * 64;
+    split = blockIdx.z;
+  }
+  const long long total = (long long)p.nstrip * p.total_rows;
+  const long long ms = (long long)split * p.rows_per_split;
+  long long me = ms + p.rows_per_split;
+  if (me > total) me = total;
+
+  const int lrow = lane >> 3;
+  const int src_chunk = (lane & 7) ^ (((lane >> 4) & 3) << 1);
+  const long long dy_row_bytes = (long long)p.dy_cstride * 2, a_row_bytes = (long long)p.a_cstride * 2;
+  const char* dy_lane = p.dY + (long long)lrow * dy_row_bytes + (long long)(p.dy_coff + n0) * 2 + src_chunk * 16;
+  const char* a_lane = p.A + (long long)lrow * a_row_bytes + (long long)(p.a_coff + k0) * 2 + src_chunk * 16;
+  const int g = lane >> 4, q = (lane >> 2) & 3, pc = lane & 3;
+  const int px = 4 * g + q;
+
+  f32x4 acc[9][4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // dY of the stage at pixel mb into buffer db; bands first .. 2 of it into their slots (rot + d) & 3
+  auto issue = [&](long long mb, int db, int rot, int first) {
+    const int ngroups = 8 + (3 - first) * C::BAND_GROUPS;
+    for (int gi = wave; gi < ngroups; gi += 4) {
+      const char* src;
+      int dst;
+      if (gi < 8) {
+        src = dy_lane + (mb + gi * 8) * dy_row_bytes;
+        dst = db * C::DY_BYTES + gi * 1024;
+      } else {
+        const int bi = (gi - 8) / C::BAND_GROUPS, bg = (gi - 8) % C::BAND_GROUPS;
+        const int d = first + bi;
+        src = a_lane + (mb + (long long)(d - 1) * p.Wp - 1 + bg * 8) * a_row_bytes;
+        dst = C::BAND_OFF + ((rot + d) & 3) * C::BAND_BYTES + bg * 1024;
+      }
+      // Written as assembly on purpose: behind the builtin the compiler puts a full s_waitcnt vmcnt(0) in front of
+      // every transposing LDS read that follows (it cannot tell which slot the DMA fills), which would undo the
+      // prefetch; the waits for these loads are the explicit ones at the end of each stage.
+      const uint32_t lds_addr = (uint32_t)(uintptr_t)(UH_LDS char*)(smem + dst);
+      asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_addr), "v"(src) : "memory");
+    }
+  };
+  auto where = [&](long long it, int& row, long long& mb) {
+    const int strip = (int)(it / p.total_rows);
+    row = (int)(it - (long long)strip * p.total_rows);
+    mb = (long long)row * p.Wp + strip * 64;
+  };
+
+  if (ms < me) {
+    int row, rot = 0, db = 0;
+    long long mb;
+    where(ms, row, mb);
+    issue(mb, 0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (long long it = ms; it < me; ++it) {
+      int row_n = 0;
+      long long mb_n = 0;
+      const bool more = it + 1 < me;
+      if (more) where(it + 1, row_n, mb_n);
+      const bool follows = more && row_n == row + 1;         // the next stage is the next image row of this strip
+      if (follows) issue(mb_n, db ^ 1, (rot + 1) & 3, 2);
+      const char* dyb = smem + db * C::DY_BYTES;
+      int boff[3];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) boff[d] = C::BAND_OFF + ((rot + d) & 3) * C::BAND_BYTES;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 af[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          bf16x4 lo, hi;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int r = ks * 32 + px + 16 * h;
+            const int chunk = (2 * i + (pc >> 1)) ^ (((r >> 1) & 3) << 1);
+            const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                (UH_LDS bf16x4*)(dyb + r * 128 + chunk * 16 + (pc & 1) * 8));
+            if (h == 0) lo = v; else hi = v;
+          }
+          af[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int band = t / 3, kx = t % 3;
+          bf16x4 lo, hi;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int r = ks * 32 + px + 16 * h + kx;
+            const int chunk = (2 * wave + (pc >> 1)) ^ (((r >> 1) & 3) << 1);
+            const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                (UH_LDS bf16x4*)(smem + boff[band] + r * 128 + chunk * 16 + (pc & 1) * 8));
+            if (h == 0) lo = v; else hi = v;
+          }
+          const bf16x8 bfr = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr, acc[t][i], 0, 0, 0);
+        }
+      }
+      if (follows) {
+        rot = (rot + 1) & 3;
+      } else if (more) {                                     // a new strip: nothing of this stage is reused
+        __syncthreads();
+        rot = 0;
+        issue(mb_n, db ^ 1, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      db ^= 1;
+      row = row_n;
+    }
+  }
+
+  const int l15 = lane & 15;
+  float* base = p.partial + (long long)split * p.N * 9 * p.K;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = n0 + i * 16 + g * 4 + e;
+        const int k = k0 + wave * 16 + l15;
+        base[((long long)n * 9 + t) * p.K + k] = acc[t][i][e];
+      }
+}
+
 static int wgrad_splits(long long Mp, int N, int K, int T) {
   const long long stages = (Mp + 127) / 128;
   const long long tiles = (long long)(N / 64) * (K / 64);
   (void)T;
-  long long want = (512 + tiles - 1) / tiles;        // aim at ~512 workgroups (two per CU): every split costs a slab
+  static const int target = [] { const char* e = getenv("UNET_AMD_WGRAD_WGS"); return e ? atoi(e) : 512; }();
+  long long want = (target + tiles - 1) / tiles;     // aim at ~512 workgroups (two per CU): every split costs a slab
   if (want > stages) want = stages;
   if (want < 1) want = 1;
   if (want > 512) want = 512;
@@ -190,6 +358,16 @@ extern "C" int uh_conv_wgrad(int B, int H, int W, const void* dy, int dy_cstride
   const int S = wgrad_splits(p.Mp, N, K, T);
   const long long stages = (p.Mp + 127) / 128;
   p.rows_per_split = ((stages + S - 1) / S) * 128;
+  // UNET_AMD_WGRAD_COLWALK=0: the linear walk of conv_wgrad_kernel everywhere (default: conv_wgrad_col_kernel wherever
+  // W is a multiple of 64)
+  static const bool colwalk_on = [] { const char* e = getenv("UNET_AMD_WGRAD_COLWALK"); return !e || atoi(e) != 0; }();
+  const bool col64 = T == 9 && W % 64 == 0 && colwalk_on;
+  p.total_rows = B * (H + 1);
+  p.nstrip = W / 64;
+  if (col64) {
+    const long long cstages = (long long)p.nstrip * p.total_rows;     // >= Mp / 128 >= S: no split is empty
+    p.rows_per_split = (cstages + S - 1) / S;
+  }
   p.dy_cstride = dy_cstride;
   p.dy_coff = dy_coff;
   p.a_cstride = a_cstride;
@@ -202,7 +380,9 @@ extern "C" int uh_conv_wgrad(int B, int H, int W, const void* dy, int dy_cstride
   dim3 grid(N / 64, K / 64, S);
   if (p.remap) grid = dim3((unsigned)(8 * ((S + 7) / 8) * (N / 64) * (K / 64)), 1, 1);
   hipStream_t st = (hipStream_t)s;
-  if (T == 9) {
+  if (col64) {
+    hipLaunchKernelGGL(conv_wgrad_col_kernel, grid, dim3(256), WColCfg::LDS_BYTES, st, p);
+  } else if (T == 9) {
     uh_set_max_lds((const void*)conv_wgrad_kernel<9>, WCfg<9>::LDS_BYTES);
     hipLaunchKernelGGL((conv_wgrad_kernel<9>), grid, dim3(256), WCfg<9>::LDS_BYTES, st, p);
   } else {
