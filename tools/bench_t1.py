@@ -21,7 +21,10 @@ for k, (hs, w) in enumerate(((16, 512), (32, 256), (64, 128), (128, 64)), 1):
     Mp = B * (hs + 1) * (hs + 1)
     fwd = lambda: call("uh_conv_gemm", B, hs, hs, a.ptr, a.cstride, 0, cin, wf.data_ptr(), 4 * w, 1, _lib.EPI_CONVT, cat.ptr, cat.cstride, w, bias.data_ptr(), None, None, None, mask.data_ptr(), S())
     dgr = lambda: call("uh_conv_gemm", B, hs, hs, d4.ptr, d4.cstride, 0, 4 * w, wf.data_ptr(), cin, 1, _lib.EPI_MASKED, da.ptr, da.cstride, 0, None, None, None, None, mask.data_ptr(), S())
-    for nm, f in (("fwd", fwd), ("dgrad", dgr)):
+    Sp = lib.uh_conv_wgrad_splits(B, hs, hs, 4 * w, cin, 1)
+    part = torch.empty(Sp * 4 * w * cin, device=DEV)
+    wgr = lambda: call("uh_conv_wgrad", B, hs, hs, d4.ptr, d4.cstride, 0, 4 * w, a.ptr, a.cstride, 0, cin, 1, part.data_ptr(), S())
+    for nm, f in (("fwd", fwd), ("dgrad", dgr), ("wgrad", wgr)):
         for _ in range(3): f()
         torch.cuda.synchronize()
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)

@@ -482,10 +482,46 @@ __global__ __launch_bounds__(256) void wgrad_reduce_oihw9_kernel(const float* __
   }
 }
 
+// The same for MANY splits of a small tensor (the full-resolution layers: 512 splits of 64 x 9 x 64): a block per
+// (n, tap, 64 k) and sixteen slices of the splits, so that the launch has thousands of waves in flight instead of
+// N * K / 64 workgroups walking 128 splits each.  The 64 results of a block go out 36 bytes apart (a 147 KB tensor).
+__global__ __launch_bounds__(1024) void wgrad_reduce_oihw9_wide_kernel(const float* __restrict__ partial, int S,
+                                                                        long long split_stride, int K,
+                                                                        float* __restrict__ grad, int accumulate) {
+  __shared__ float red[16][64];
+  const int n = blockIdx.z, t = blockIdx.y, k0 = blockIdx.x * 64;
+  const int kk = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const float* q = partial + ((long long)n * 9 + t) * K + k0 + kk;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int sp = sl;
+  for (; sp + 48 < S; sp += 64) {
+    a0 += q[sp * split_stride];
+    a1 += q[(sp + 16) * split_stride];
+    a2 += q[(sp + 32) * split_stride];
+    a3 += q[(sp + 48) * split_stride];
+  }
+  for (; sp < S; sp += 16) a0 += q[sp * split_stride];
+  red[sl][kk] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (sl == 0) {
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v += red[j][kk];
+    float* dst = grad + ((long long)n * K + k0 + kk) * 9 + t;
+    *dst = accumulate ? *dst + v : v;
+  }
+}
+
 extern "C" int uh_wgrad_reduce_strided(const float* partial, int S, long long split_stride, int N, int T, int K,
                                        long long on, long long ot, long long sn, long long st, long long sk,
                                        float* grad, int accumulate, uh_stream s) {
   UH_REQUIRE(partial && grad && S > 0 && N > 0 && T > 0 && K > 0 && split_stride > 0, "wgrad_reduce: bad arguments");
+  if (T == 9 && K % 64 == 0 && on == 9LL * K && ot == K && sn == 9LL * K && st == 1 && sk == 9 && N <= 65535 &&
+      S >= 64) {
+    hipLaunchKernelGGL(wgrad_reduce_oihw9_wide_kernel, dim3(K / 64, 9, N), dim3(1024), 0, (hipStream_t)s, partial, S,
+                       split_stride, K, grad, accumulate);
+    return uh_check_launch("wgrad_reduce");
+  }
   if (T == 9 && K % 64 == 0 && on == 9LL * K && ot == K && sn == 9LL * K && st == 1 && sk == 9 && N <= 65535) {
     hipLaunchKernelGGL(wgrad_reduce_oihw9_kernel, dim3(K / 64, N), dim3(256), 0, (hipStream_t)s, partial, S,
                        split_stride, K, grad, accumulate);
