@@ -198,6 +198,13 @@ int uh_maxpool2_bwd_bnstat(int B, int H, int W, int C, const void* a, int a_cstr
  * into a T=1 GEMM operand. */
 int uh_space_to_depth2(int B, int H, int W, int C, const void* in, int i_cstride, int i_coff,
                        void* out, int o_cstride, int o_coff, uh_stream s);
+/* The same pair with a large geometry of (B, bigH, bigW), bigH in {2H, 2H+1}, bigW in {2W, 2W+1}: a k2 s2 convolution
+ * ignores the last row / column of an odd-sized input (lunext.py:139-154 on sizes not divisible by 16), and the
+ * inverse scatter writes zeros there. */
+int uh_space_to_depth2_of(int B, int H, int W, int C, int bigH, int bigW, const void* in, int i_cstride, int i_coff,
+                          void* out, int o_cstride, int o_coff, uh_stream s);
+int uh_depth_to_space2_to(int B, int H, int W, int C, int bigH, int bigW, const void* in, int i_cstride, int i_coff,
+                          void* out, int o_cstride, int o_coff, uh_stream s);
 /* inverse scatter: out[(b,2y+t/2,2x+t%2)][c] = in[(b,y,x)][t*C + c], pads of out zero */
 int uh_depth_to_space2(int B, int H, int W, int C, const void* in, int i_cstride, int i_coff,
                        void* out, int o_cstride, int o_coff, uh_stream s);
@@ -276,6 +283,14 @@ int uh_dwblock_bwd(int B, int H, int W, int C, const void* da, int da_cstride, i
                    const float* w, int c_real,
                    const float* mean, const float* invstd, const float* scale, const float* shift, const float* coef,
                    void* dx, int dx_cstride, int dx_coff, float* partial, uh_stream s);
+
+/* F.interpolate(x, size=(Ho, Wo), mode='bilinear', align_corners=False) and its backward (lunext.py:226-251: the
+ * size fix after a transposed convolution when the skip connection is one row / column larger), padded-linear NHWC
+ * bf16 on both sides, fp32 arithmetic with torch's source-index rule. */
+int uh_resize_bilinear_fwd(int B, int Hi, int Wi, int Ho, int Wo, int C, const void* in, int i_cstride, int i_coff,
+                           void* out, int o_cstride, int o_coff, uh_stream s);
+int uh_resize_bilinear_bwd(int B, int Hi, int Wi, int Ho, int Wo, int C, const void* dout, int o_cstride, int o_coff,
+                           void* din, int i_cstride, int i_coff, uh_stream s);
 /* fully fused gate for the 8-channel top level; wts = W1[8][8]|W2[8][8]|W3[8][8]|b1[8]|b2[8]|b3[8] fp32
  * ([co][ci], zero beyond the c_real real channels; only those are computed),
  * partial[blk][216] (blk < uh_gate8_parts) holds the weight gradients in the same layout */

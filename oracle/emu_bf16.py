@@ -96,6 +96,8 @@ class EmuLUNeXt(ref_cpu.RefLUNeXt):
         for k in range(1, 5):
             up = getattr(self, f"upconv{k}")
             u = q(F.conv_transpose2d(x, w_bf16(up.weight), up.bias, stride=2), torch.bfloat16)
+            if u.shape != skips[4 - k].shape:                # lunext.py:226-227: stored again after the size fix
+                u = q(F.interpolate(u, size=skips[4 - k].shape[2:], mode="bilinear", align_corners=False), torch.bfloat16)
             x = self._gate(getattr(self, f"att{k}"), u, skips[4 - k])
             x = self._dwb(getattr(self, f"conv_up{k}_2"), self._dwb(getattr(self, f"conv_up{k}_1"), x))
         return self.final_conv(x)

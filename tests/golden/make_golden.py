@@ -170,6 +170,36 @@ def lunext_small():
     print("lunext_s0_b2_32: loss", fx["train_loss"])
 
 
+def lunext_odd():
+    """A size that is not divisible by 16: 44x52 -> 22x26 -> 11x13 -> 5x6 -> 2x3, so the transposed convolutions of the
+    two deepest decoder stages return 4x6 and 10x12 where the skip connections are 5x6 and 11x13 (lunext.py:226-235)."""
+    from oracle import ref_cpu
+    torch.manual_seed(1)
+    model = LUNeXt(3, 1)
+    x, m = rand_inputs(2, 3, 44, 52, seed=17)
+    import copy
+    oracle = ref_cpu.RefLUNeXt(3, 1)
+    oracle.load_state_dict(model.state_dict())
+    assert torch.equal(copy.deepcopy(model)(x), oracle(x)), "oracle != reference on the size-fix path"
+    crit = soft_dice_cldice()
+    model.train()
+    logits = model(x)
+    loss = crit(m, torch.sigmoid(logits).clamp(1e-6, 1 - 1e-6))
+    loss.backward()
+    fx = {"x": x.numpy(), "mask": m.numpy(), "param_checksums": param_checksums(model),
+          "train_logits": logits.detach().numpy(), "train_loss": np.float64(loss.item()),
+          "grad_summary": grad_summary(model),
+          "param_names": np.array([n for n, _ in model.named_parameters()])}
+    for n, p in model.named_parameters():
+        if p.grad is not None and (p.numel() <= 4096 or n == "upconv3.weight"):
+            fx["grad/" + n] = p.grad.numpy().copy()
+    model.eval()
+    with torch.no_grad():
+        fx["eval_logits"] = model(x).numpy()
+    np.savez_compressed(os.path.join(HERE, "lunext_s1_b2_44x52.npz"), **fx)
+    print("lunext_s1_b2_44x52: loss", fx["train_loss"])
+
+
 def cldice_cases():
     sk = SoftSkeletonize(num_iter=10)
     crit = soft_dice_cldice()
@@ -270,4 +300,5 @@ if __name__ == "__main__":
     unet_small()
     unet_in2()
     lunext_small()
+    lunext_odd()
     unet_adam_128()

@@ -813,6 +813,50 @@ def test_head_backward_with_batchnorm_backward_sums(B, H, W, C, OC):
     assert ((got - want).abs() <= 1e-5 * mag.max() * 8 + 1e-6).all()
 
 
+@pytest.mark.parametrize("B,Hi,Wi,Ho,Wo,C", [(2, 4, 6, 5, 6, 64), (1, 10, 12, 11, 13, 8), (2, 8, 8, 8, 9, 128),
+                                             (1, 6, 6, 12, 12, 64), (1, 9, 7, 4, 5, 8)])
+def test_bilinear_resize_forward_backward(B, Hi, Wi, Ho, Wo, C):
+    """uh_resize_bilinear_fwd/bwd against F.interpolate(mode='bilinear', align_corners=False) and its autograd"""
+    g = torch.Generator().manual_seed(79)
+    x = bf(torch.randn(B, C, Hi, Wi, generator=g))
+    dout = bf(torch.randn(B, C, Ho, Wo, generator=g))
+    xa, da = act_from(x, cstride=2 * C, coff=C), act_from(dout)
+    out, dx = new_act(B, Ho, Wo, C, DEV), new_act(B, Hi, Wi, C, DEV)
+    out.padded_rows()[:, :] = 3.0
+    dx.padded_rows()[:, :] = 3.0
+    call("uh_resize_bilinear_fwd", B, Hi, Wi, Ho, Wo, C, xa.ptr, xa.cstride, xa.coff, out.ptr, out.cstride, out.coff, S())
+    call("uh_resize_bilinear_bwd", B, Hi, Wi, Ho, Wo, C, da.ptr, da.cstride, da.coff, dx.ptr, dx.cstride, dx.coff, S())
+    torch.cuda.synchronize()
+    xr = x.clone().requires_grad_(True)
+    want = F.interpolate(xr, size=(Ho, Wo), mode="bilinear", align_corners=False)
+    want.backward(dout)
+    close(out.to_nchw(), want, 5e-3, "resize fwd")
+    close(dx.to_nchw(), xr.grad, 5e-3, "resize bwd")
+    pads_are_zero(out)
+    pads_are_zero(dx)
+
+
+@pytest.mark.parametrize("B,h,w,bigH,bigW,C", [(2, 3, 4, 7, 8, 64), (1, 5, 6, 11, 13, 8), (2, 2, 2, 4, 5, 16)])
+def test_space_to_depth_of_odd_sizes(B, h, w, bigH, bigW, C):
+    g = torch.Generator().manual_seed(83)
+    x = bf(torch.randn(B, C, bigH, bigW, generator=g))
+    xa = act_from(x)
+    x4 = new_act(B, h, w, 4 * C, DEV)
+    call("uh_space_to_depth2_of", B, h, w, C, bigH, bigW, xa.ptr, xa.cstride, xa.coff, x4.ptr, x4.cstride, 0, S())
+    back = new_act(B, bigH, bigW, C, DEV)
+    back.padded_rows()[:, :] = 3.0
+    call("uh_depth_to_space2_to", B, h, w, C, bigH, bigW, x4.ptr, x4.cstride, 0, back.ptr, back.cstride, back.coff, S())
+    torch.cuda.synchronize()
+    got = x4.to_nchw().view(B, 4, C, h, w)                    # channel index t*C + c, t = 2*dy + dx
+    for t in range(4):
+        assert torch.equal(got[:, t].cpu(), x[:, :, t // 2:2 * h:2, t % 2:2 * w:2])
+    pads_are_zero(x4)
+    want = torch.zeros_like(x)
+    want[:, :, :2 * h, :2 * w] = x[:, :, :2 * h, :2 * w]      # the dropped row / column gets zeros
+    assert torch.equal(back.to_nchw().cpu(), want)
+    pads_are_zero(back)
+
+
 # ---- AttentionGate kernels (lunext.py:76-122) ---------------------------------------------------------------------
 @pytest.mark.parametrize("B,H,W,C", [(2, 8, 8, 64), (1, 6, 10, 128), (2, 4, 4, 256)])
 def test_gate_pointwise_forward_backward(B, H, W, C):

@@ -113,6 +113,36 @@ def test_lunext_golden_small(golden_dir):
     assert (ev - want_ev).abs().max().item() <= LOGIT_REL * want_ev.abs().max().item()
 
 
+def test_lunext_size_not_divisible_by_16(golden_dir):
+    """44x52 -> 22x26 -> 11x13 -> 5x6 -> 2x3: the k2 s2 convolutions drop a row / column twice, and the two deepest
+    decoder stages resize what the transposed convolution returns (lunext.py:226-235).  Against the fixture captured
+    from the reference and, for the gradients, against the oracle with the emulation as yardstick."""
+    fx = np.load(os.path.join(golden_dir, "lunext_s1_b2_44x52.npz"), allow_pickle=False)
+    x, m = torch.from_numpy(fx["x"]), torch.from_numpy(fx["mask"])
+    o = three_way(2, 3, 44, 52, "cldice", seed=1, x=x, m=m)
+    # the same weights as the fixture (bit-equal on the machine the fixture was made on: tests/test_oracle_golden.py)
+    np.testing.assert_allclose(o["ref"]["logits"].numpy(), fx["train_logits"], rtol=1e-4, atol=1e-5)
+    want = torch.from_numpy(fx["train_logits"])
+    err = (o["hip"]["logits"] - want).abs().max().item()
+    print(f"logits max err {err:.4g} (max |ref| {want.abs().max().item():.4g})")
+    assert err <= LOGIT_REL * want.abs().max().item()
+    assert abs(o["hip"]["loss"] - float(fx["train_loss"])) <= LOSS_REL * float(fx["train_loss"])
+    # B = 2 at 2x3: the bridge BatchNorm sees 12 samples per channel (see test_lunext_golden_small)
+    yardstick(o, "44x52", min_numel=64, skip=("downconv4", "conv5_1", "conv5_2"))
+    model = o["hip"]["net"].eval()
+    with torch.no_grad():
+        ev = model(x.to(DEV)).cpu()
+    want_ev = torch.from_numpy(fx["eval_logits"])
+    assert (ev - want_ev).abs().max().item() <= LOGIT_REL * want_ev.abs().max().item()
+
+
+@pytest.mark.parametrize("H,W", [(17, 16), (30, 50), (100, 76)])
+def test_lunext_odd_sizes_against_the_oracle(H, W):
+    o = three_way(2, 3, H, W, "bce", seed=5)
+    err_hip, scale = yardstick(o, f"{H}x{W}", min_numel=64, skip=("downconv4", "conv5_1", "conv5_2", "upconv1"))
+    assert err_hip <= LOGIT_REL * scale
+
+
 def three_way(B, C, H, W, loss, seed=4, x=None, m=None):
     """one training step of the fp32 oracle, the oracle with 16-bit storage roundings, and the HIP module"""
     from oracle import emu_bf16
@@ -218,7 +248,7 @@ def test_lunext_eval_and_surface():
         assert (got - want).abs().max().item() <= LOGIT_REL * want.abs().max().item()
         one = model(x[:1].to(DEV)).cpu()
         assert (one - want[:1]).abs().max().item() <= LOGIT_REL * want.abs().max().item()
-    with pytest.raises(NotImplementedError, match="divisible by 16"):
-        model(torch.rand(1, 3, 20, 16, device=DEV))
+    with pytest.raises(ValueError, match="at least 16"):
+        model(torch.rand(1, 3, 20, 12, device=DEV))
     with pytest.raises(RuntimeError, match="HIP kernels only"):
         model(torch.rand(1, 3, 16, 16))

@@ -122,6 +122,27 @@ def test_lunext_small_matches_reference(golden_dir):
         np.testing.assert_allclose(model(x).numpy(), fx["eval_logits"], rtol=1e-6, atol=1e-7)
 
 
+def test_lunext_size_not_divisible_by_16_matches_reference(golden_dir):
+    """44x52: the two deepest decoder stages go through the bilinear size fix (lunext.py:226-235)"""
+    fx = _load(golden_dir, "lunext_s1_b2_44x52.npz")
+    torch.manual_seed(1)
+    model = ref_cpu.RefLUNeXt(3, 1)
+    x, m = torch.from_numpy(fx["x"]), torch.from_numpy(fx["mask"])
+    model.train()
+    logits = model(x)
+    loss = ref_cpu.RefSoftDiceClDice()(m, ref_cpu.probs_from_logits(logits))
+    loss.backward()
+    np.testing.assert_array_equal(logits.detach().numpy(), fx["train_logits"])
+    assert loss.item() == float(fx["train_loss"])
+    gs = fx["grad_summary"]
+    for i, (n, p) in enumerate(model.named_parameters()):
+        if not np.isnan(gs[i, 0]):
+            np.testing.assert_allclose(p.grad.double().norm().item(), gs[i, 0], rtol=1e-5, atol=1e-10, err_msg=n)
+    model.eval()
+    with torch.no_grad():
+        np.testing.assert_allclose(model(x).numpy(), fx["eval_logits"], rtol=1e-6, atol=1e-7)
+
+
 def test_cldice_cases_match_reference(golden_dir):
     fx = _load(golden_dir, "cldice_cases.npz")
     crit = ref_cpu.RefSoftDiceClDice()

@@ -72,6 +72,10 @@ SIGNATURES = {
     "uh_dwconv3x3_dgrad": (I, [I, I, I, I, P, I, I, P, I, P, I, I, P, P, I, I, P]),
     "uh_dwconv3x3_wgrad": (I, [I, I, I, I, P, I, I, P, I, I, P, P]),
     "uh_dw_wgrad_finalize": (I, [P, I, I, I, P, P]),
+    "uh_space_to_depth2_of": (I, [I, I, I, I, I, I, P, I, I, P, I, I, P]),
+    "uh_depth_to_space2_to": (I, [I, I, I, I, I, I, P, I, I, P, I, I, P]),
+    "uh_resize_bilinear_fwd": (I, [I, I, I, I, I, I, P, I, I, P, I, I, P]),
+    "uh_resize_bilinear_bwd": (I, [I, I, I, I, I, I, P, I, I, P, I, I, P]),
     "uh_dwblock_bwd_parts": (I, [I, I, I, I]),
     "uh_dwblock_bwd": (I, [I, I, I, I, P, I, I, P, I, I, P, I, I, P, I, P, P, P, P, P, P, I, I, P, P]),
     "uh_gate_fwd": (I, [L, I, P, I, I, P, I, I, P, I, I, P]),

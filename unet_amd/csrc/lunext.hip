@@ -1010,6 +1010,123 @@ extern "C" int uh_gate8_bwd(long long Mp, int c_real, const void* dout, int d_cs
   return uh_check_launch("gate8_bwd");
 }
 
+// ---- bilinear resize, align_corners = False (the size fix after a transposed convolution, lunext.py:226-251) ------------
+// torch's rule: src = (dst + 0.5) * in/out - 0.5, clamped at 0; i0 = floor(src), i1 = min(i0 + 1, in - 1), l1 = src - i0.
+struct Lerp {
+  int i0, i1;
+  float l0, l1;
+};
+__device__ __forceinline__ Lerp lerp_of(int dst, float scale, int in_size) {
+  float src = scale * ((float)dst + 0.5f) - 0.5f;
+  src = src < 0.f ? 0.f : src;
+  Lerp r;
+  r.i0 = (int)src;
+  if (r.i0 > in_size - 1) r.i0 = in_size - 1;
+  r.i1 = r.i0 + (r.i0 < in_size - 1 ? 1 : 0);
+  r.l1 = src - (float)r.i0;
+  r.l0 = 1.f - r.l1;
+  return r;
+}
+
+__global__ __launch_bounds__(256) void resize_bilinear_fwd_kernel(int B, int Hi, int Wi, int Ho, int Wo, int C,
+                                                                  const char* __restrict__ in, int i_cs, int i_co,
+                                                                  char* __restrict__ out, int o_cs, int o_co) {
+  const int cpr = C / 8, oWp = Wo + 1, oHp = Ho + 1, iWp = Wi + 1, iHp = Hi + 1;
+  const long long total = (long long)B * oHp * oWp * cpr;
+  const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int cc = (int)(i % cpr);
+    const long long m = i / cpr;
+    const int x = (int)(m % oWp);
+    const long long r = m / oWp;
+    const int y = (int)(r % oHp);
+    const long long b = r / oHp;
+    U4 o = {0u, 0u, 0u, 0u};
+    if (y < Ho && x < Wo) {
+      const Lerp ly = lerp_of(y, sy, Hi), lx = lerp_of(x, sx, Wi);
+      const long long base = b * iHp;
+      float v00[8], v01[8], v10[8], v11[8], f[8];
+      unpack8(*(const U4*)(in + ((((base + ly.i0) * iWp + lx.i0) * i_cs) + i_co + cc * 8) * 2), v00);
+      unpack8(*(const U4*)(in + ((((base + ly.i0) * iWp + lx.i1) * i_cs) + i_co + cc * 8) * 2), v01);
+      unpack8(*(const U4*)(in + ((((base + ly.i1) * iWp + lx.i0) * i_cs) + i_co + cc * 8) * 2), v10);
+      unpack8(*(const U4*)(in + ((((base + ly.i1) * iWp + lx.i1) * i_cs) + i_co + cc * 8) * 2), v11);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        f[j] = ly.l0 * (lx.l0 * v00[j] + lx.l1 * v01[j]) + ly.l1 * (lx.l0 * v10[j] + lx.l1 * v11[j]);
+      o = pack8(f);
+    }
+    *(U4*)(out + (m * o_cs + o_co + cc * 8) * 2) = o;
+  }
+}
+
+// The transpose: every input position gathers, in a fixed order, from the output positions that read it.
+__global__ __launch_bounds__(256) void resize_bilinear_bwd_kernel(int B, int Hi, int Wi, int Ho, int Wo, int C,
+                                                                  const char* __restrict__ dout, int o_cs, int o_co,
+                                                                  char* __restrict__ din, int i_cs, int i_co) {
+  const int cpr = C / 8, oWp = Wo + 1, oHp = Ho + 1, iWp = Wi + 1, iHp = Hi + 1;
+  const long long total = (long long)B * iHp * iWp * cpr;
+  const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int cc = (int)(i % cpr);
+    const long long m = i / cpr;
+    const int x = (int)(m % iWp);
+    const long long r = m / iWp;
+    const int y = (int)(r % iHp);
+    const long long b = r / iHp;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (y < Hi && x < Wi) {
+      // output rows whose source lies in (y - 1, y + 1): a window around y / scale, widened by two for rounding
+      int ylo = (int)floorf(((float)y - 1.f + 0.5f) / sy - 0.5f) - 1, yhi = (int)ceilf(((float)y + 1.f + 0.5f) / sy - 0.5f) + 1;
+      int xlo = (int)floorf(((float)x - 1.f + 0.5f) / sx - 0.5f) - 1, xhi = (int)ceilf(((float)x + 1.f + 0.5f) / sx - 0.5f) + 1;
+      ylo = ylo < 0 ? 0 : ylo;
+      xlo = xlo < 0 ? 0 : xlo;
+      yhi = yhi > Ho - 1 ? Ho - 1 : yhi;
+      xhi = xhi > Wo - 1 ? Wo - 1 : xhi;
+      for (int oy = ylo; oy <= yhi; ++oy) {
+        const Lerp ly = lerp_of(oy, sy, Hi);
+        const float wy = (ly.i0 == y ? ly.l0 : 0.f) + (ly.i1 == y ? ly.l1 : 0.f);
+        if (wy == 0.f) continue;
+        for (int ox = xlo; ox <= xhi; ++ox) {
+          const Lerp lx = lerp_of(ox, sx, Wi);
+          const float wx = (lx.i0 == x ? lx.l0 : 0.f) + (lx.i1 == x ? lx.l1 : 0.f);
+          if (wx == 0.f) continue;
+          float g[8];
+          unpack8(*(const U4*)(dout + ((((b * oHp + oy) * oWp + ox) * o_cs) + o_co + cc * 8) * 2), g);
+          const float wgt = wy * wx;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] = fmaf(wgt, g[j], acc[j]);
+        }
+      }
+    }
+    *(U4*)(din + (m * i_cs + i_co + cc * 8) * 2) = pack8(acc);
+  }
+}
+
+static int resize_launch(bool fwd, int B, int Hi, int Wi, int Ho, int Wo, int C, const void* src, int s_cs, int s_co,
+                         void* dst, int d_cs, int d_co, uh_stream s) {
+  EW_CHECK("resize_bilinear", C);
+  UH_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && src && dst, "resize_bilinear: bad arguments");
+  UH_REQUIRE(s_cs % 8 == 0 && s_co % 8 == 0 && d_cs % 8 == 0 && d_co % 8 == 0, "resize_bilinear: bad views");
+  const long long total = (fwd ? uh_mp(B, Ho, Wo) : uh_mp(B, Hi, Wi)) * (C / 8);
+  long long blocks = (total + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  if (fwd)
+    hipLaunchKernelGGL(resize_bilinear_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, B, Hi, Wi, Ho, Wo,
+                       C, (const char*)src, s_cs, s_co, (char*)dst, d_cs, d_co);
+  else
+    hipLaunchKernelGGL(resize_bilinear_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, B, Hi, Wi, Ho, Wo,
+                       C, (const char*)src, s_cs, s_co, (char*)dst, d_cs, d_co);
+  return uh_check_launch("resize_bilinear");
+}
+extern "C" int uh_resize_bilinear_fwd(int B, int Hi, int Wi, int Ho, int Wo, int C, const void* in, int i_cstride,
+                                      int i_coff, void* out, int o_cstride, int o_coff, uh_stream s) {
+  return resize_launch(true, B, Hi, Wi, Ho, Wo, C, in, i_cstride, i_coff, out, o_cstride, o_coff, s);
+}
+extern "C" int uh_resize_bilinear_bwd(int B, int Hi, int Wi, int Ho, int Wo, int C, const void* dout, int o_cstride,
+                                      int o_coff, void* din, int i_cstride, int i_coff, uh_stream s) {
+  return resize_launch(false, B, Hi, Wi, Ho, Wo, C, dout, o_cstride, o_coff, din, i_cstride, i_coff, s);
+}
+
 // ---- NCHW fp32 image <-> 8-channel padded-linear bf16 (the top level of LUNeXt reads the image directly) ----------------
 __global__ __launch_bounds__(256) void nchw_to_c8_kernel(int B, int Cin, int H, int W, const float* __restrict__ x,
                                                          char* __restrict__ out, int o_cs, int o_co) {

@@ -139,10 +139,12 @@ extern "C" int uh_pack_weights_multi(const uh_pack_desc* descs_device, int count
 // ---- space <-> depth for k2 s2 (transposed) convolutions -------------------------------------
 // Small geometry (B,H,W); large geometry (B,2H,2W).  One thread moves 8 channels of one
 // (small position, tap); every row of the destination, pads included, is written exactly once.
+// The large geometry may also be (B, 2H+1, 2W+1): a k2 s2 convolution drops the last row / column of an odd-sized
+// input, and their gradient is zero (bigH, bigW are the large geometry's own H and W).
 template <bool TO_DEPTH>
-__global__ void s2d_kernel(int B, int H, int W, int C, const char* __restrict__ in, int i_cstride, int i_coff,
-                           char* __restrict__ out, int o_cstride, int o_coff) {
-  const unsigned Wp = W + 1, Hp = H + 1, oWp = 2 * W + 1, oHp = 2 * H + 1;
+__global__ void s2d_kernel(int B, int H, int W, int C, int bigH, int bigW, const char* __restrict__ in, int i_cstride,
+                           int i_coff, char* __restrict__ out, int o_cstride, int o_coff) {
+  const unsigned Wp = W + 1, Hp = H + 1, oWp = bigW + 1, oHp = bigH + 1;
   const unsigned cpr = C / 8;
   const unsigned total = (unsigned)B * Hp * Wp * cpr;                    // the host checks that this fits
   // one thread moves the four taps of a (row, 8-channel chunk): one decode, four loads in flight
@@ -179,30 +181,40 @@ __global__ void s2d_kernel(int B, int H, int W, int C, const char* __restrict__ 
   }
 }
 
-static int s2d_launch(bool to_depth, int B, int H, int W, int C, const void* in, int i_cstride, int i_coff, void* out,
-                      int o_cstride, int o_coff, uh_stream s) {
+static int s2d_launch(bool to_depth, int B, int H, int W, int C, int bigH, int bigW, const void* in, int i_cstride,
+                      int i_coff, void* out, int o_cstride, int o_coff, uh_stream s) {
   UH_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && in && out, "space/depth: bad arguments");
+  UH_REQUIRE((bigH == 2 * H || bigH == 2 * H + 1) && (bigW == 2 * W || bigW == 2 * W + 1),
+             "space/depth: large geometry %dx%d does not halve to %dx%d", bigH, bigW, H, W);
   UH_REQUIRE(i_cstride % 8 == 0 && i_coff % 8 == 0 && o_cstride % 8 == 0 && o_coff % 8 == 0, "space/depth: bad views");
   const long long total = uh_mp(B, H, W) * (C / 8);
   UH_REQUIRE(total < (1ll << 31), "space/depth: %lld items", total);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 16384) blocks = 16384;
   if (to_depth)
-    hipLaunchKernelGGL((s2d_kernel<true>), dim3(blocks), dim3(256), 0, (hipStream_t)s, B, H, W, C, (const char*)in,
+    hipLaunchKernelGGL((s2d_kernel<true>), dim3(blocks), dim3(256), 0, (hipStream_t)s, B, H, W, C, bigH, bigW, (const char*)in,
                        i_cstride, i_coff, (char*)out, o_cstride, o_coff);
   else
-    hipLaunchKernelGGL((s2d_kernel<false>), dim3(blocks), dim3(256), 0, (hipStream_t)s, B, H, W, C, (const char*)in,
+    hipLaunchKernelGGL((s2d_kernel<false>), dim3(blocks), dim3(256), 0, (hipStream_t)s, B, H, W, C, bigH, bigW, (const char*)in,
                        i_cstride, i_coff, (char*)out, o_cstride, o_coff);
   return uh_check_launch("space/depth");
 }
 
 extern "C" int uh_space_to_depth2(int B, int H, int W, int C, const void* in, int i_cstride, int i_coff, void* out,
                                   int o_cstride, int o_coff, uh_stream s) {
-  return s2d_launch(true, B, H, W, C, in, i_cstride, i_coff, out, o_cstride, o_coff, s);
+  return s2d_launch(true, B, H, W, C, 2 * H, 2 * W, in, i_cstride, i_coff, out, o_cstride, o_coff, s);
+}
+extern "C" int uh_space_to_depth2_of(int B, int H, int W, int C, int bigH, int bigW, const void* in, int i_cstride,
+                                     int i_coff, void* out, int o_cstride, int o_coff, uh_stream s) {
+  return s2d_launch(true, B, H, W, C, bigH, bigW, in, i_cstride, i_coff, out, o_cstride, o_coff, s);
 }
 extern "C" int uh_depth_to_space2(int B, int H, int W, int C, const void* in, int i_cstride, int i_coff, void* out,
                                   int o_cstride, int o_coff, uh_stream s) {
-  return s2d_launch(false, B, H, W, C, in, i_cstride, i_coff, out, o_cstride, o_coff, s);
+  return s2d_launch(false, B, H, W, C, 2 * H, 2 * W, in, i_cstride, i_coff, out, o_cstride, o_coff, s);
+}
+extern "C" int uh_depth_to_space2_to(int B, int H, int W, int C, int bigH, int bigW, const void* in, int i_cstride,
+                                     int i_coff, void* out, int o_cstride, int o_coff, uh_stream s) {
+  return s2d_launch(false, B, H, W, C, bigH, bigW, in, i_cstride, i_coff, out, o_cstride, o_coff, s);
 }
 
 // ---- Adam over one flat parameter buffer (torch.optim.Adam defaults, trainer/training_utils.py:107) ------------

@@ -65,13 +65,14 @@ class LUNeXtRun:
         self.pool = pool_for(x.device)
         self.lease = self.pool.lease()
         B, Cin, H, W = x.shape
-        if H % 16 or W % 16:
-            raise NotImplementedError("LUNeXt kernels need H and W divisible by 16 (the reference's bilinear "
-                                      f"size-fix branch, lunext.py:225-251, is not built); got {H}x{W}")
+        if H < 16 or W < 16:
+            raise ValueError(f"LUNeXt halves the image four times: H and W must be at least 16, got {H}x{W}")
         if Cin != module.in_channels or Cin > 8:
             raise ValueError(f"expected {module.in_channels} (<= 8) input channels, got {Cin}")
         self.x = x
         self.B = B
+        # a k2 s2 convolution floors odd sizes (lunext.py:139-154); the decoder then resizes what the transposed
+        # convolution returns to the skip connection's size (lunext.py:226-251)
         self.geo = [(B, H >> l, W >> l) for l in range(5)]
         self.masks = [self.pool.rowmask(*g) for g in self.geo]
         self.chans = [Cin, 64, 128, 256, 512]
@@ -181,7 +182,7 @@ class LUNeXtRun:
         K = max(64, 4 * cpi)
         s, Ls = self._sh, self.lease
         x4 = Ls.act(Bs, Hs, Ws, K, tag=f"down{l}.x4")
-        call("uh_space_to_depth2", Bs, Hs, Ws, cpi, x.ptr, x.cstride, x.coff, x4.ptr, x4.cstride, 0, s)
+        call("uh_space_to_depth2_of", Bs, Hs, Ws, cpi, x.H, x.W, x.ptr, x.cstride, x.coff, x4.ptr, x4.cstride, 0, s)
         wp = self.wf[f"down{l}"]
         out = Ls.act(Bs, Hs, Ws, cout)
         call("uh_conv_gemm", Bs, Hs, Ws, x4.ptr, x4.cstride, 0, K, wp.data_ptr(), cout, 1, EPI_MASKED, out.ptr,
@@ -213,7 +214,7 @@ class LUNeXtRun:
              dx4.cstride, 0, None, None, None, None, self.masks[l].data_ptr(), s)
         B, H, W = self.geo[l - 1]
         dx = Ls.act(B, H, W, cpi)
-        call("uh_depth_to_space2", Bs, Hs, Ws, cpi, dx4.ptr, dx4.cstride, 0, dx.ptr, dx.cstride, dx.coff, s)
+        call("uh_depth_to_space2_to", Bs, Hs, Ws, cpi, H, W, dx4.ptr, dx4.cstride, 0, dx.ptr, dx.cstride, dx.coff, s)
         return dx
 
     # ------------------------------------------------------------------ transposed conv (lunext.py:161-179)
@@ -227,11 +228,17 @@ class LUNeXtRun:
         Bs, Hs, Ws = self.geo[l + 1]
         s, Ls = self._sh, self.lease
         wp = self.wf[f"up{k}"]
-        out = Ls.act(*self.geo[l], cpo)
+        B, H, W = self.geo[l]
+        out = Ls.act(B, 2 * Hs, 2 * Ws, cpo)
         bias = _padv(up.bias, cpo)
         call("uh_conv_gemm", Bs, Hs, Ws, x.ptr, x.cstride, x.coff, cin, wp.data_ptr(), N, 1, EPI_CONVT, out.ptr,
              out.cstride, out.coff, bias.data_ptr(), None, None, None, self.masks[l + 1].data_ptr(), s)
         self.saved[f"up{k}"] = (x, N)
+        if (2 * Hs, 2 * Ws) != (H, W):                     # lunext.py:226-227 (and :234, :242, :250)
+            fit = Ls.act(B, H, W, cpo)
+            call("uh_resize_bilinear_fwd", B, 2 * Hs, 2 * Ws, H, W, cpo, out.ptr, out.cstride, out.coff, fit.ptr,
+                 fit.cstride, fit.coff, s)
+            return fit
         return out
 
     @ranged(lambda k, *a: f"bwd/upconv{k}")
@@ -242,6 +249,12 @@ class LUNeXtRun:
         cin, cout, cpo = self.chans[l + 1], self.chans[l], self.cp[l]
         Bs, Hs, Ws = self.geo[l + 1]
         s, Ls = self._sh, self.lease
+        B, H, W = self.geo[l]
+        if (2 * Hs, 2 * Ws) != (H, W):                     # back through the size fix
+            raw = Ls.act(B, 2 * Hs, 2 * Ws, cpo)
+            call("uh_resize_bilinear_bwd", B, 2 * Hs, 2 * Ws, H, W, cpo, dup.ptr, dup.cstride, dup.coff, raw.ptr,
+                 raw.cstride, raw.coff, s)
+            dup = raw
         grads[f"upconv{k}.bias"] = self._colsum(dup, cpo)[:cout]           # a view of a tensor made for this gradient
         d4 = Ls.act(Bs, Hs, Ws, N, tag=f"up{k}.d4")
         call("uh_space_to_depth2", Bs, Hs, Ws, cpo, dup.ptr, dup.cstride, dup.coff, d4.ptr, d4.cstride, 0, s)
