@@ -28,7 +28,11 @@ __device__ __forceinline__ float first_tap(const float* __restrict__ x, int H, i
   const int kx = r - ky * 3;
   const int yy = py + ky - 1, xx = px + kx - 1;
   const bool ok = pixel_ok && k < CIN * 9 && yy >= 0 && yy < H && xx >= 0 && xx < W;
-  return ok ? x[((b * CIN + ci) * H + yy) * W + xx] : 0.f;
+  // The load is unconditional (from element 0 where the tap does not exist): as `ok ? x[i] : 0` it is compiled into a
+  // branch per tap, and the eight taps of a pixel then cost eight memory round trips one after the other.
+  const long long i = ok ? ((b * CIN + ci) * H + yy) * W + xx : 0;
+  const float v = x[i];
+  return ok ? v : 0.f;
 }
 
 template <int CIN>
@@ -45,7 +49,7 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(int B, int H, int W
   const int l15 = lane & 15, g = lane >> 4;
   const int Wp = W + 1, Hp = H + 1;
   const long long Mp = (long long)B * Hp * Wp;
-  const long long mwave = (long long)blockIdx.x * 512 + wave * 128;
+  const long long nblk = (Mp + 511) / 512;         // a workgroup walks blocks of 512 positions: blockIdx.x, + gridDim.x, ...
 
   // weight fragments (A operand): tile j, row r = l15 is output channel (r/4)*16 + j*4 + r%4
   bf16x8 whi[NKB][4], wlo[NKB][4];
@@ -80,12 +84,18 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(int B, int H, int W
 #pragma unroll
   for (int q = 0; q < 16; ++q) s1[q] = s2[q] = 0.f;
 
-  for (int tile = 0; tile < 8; ++tile) {
-    const long long m = mwave + tile * 16 + l15;
-    const int px = (int)(m % Wp);
-    const long long r = m / Wp;
-    const int py = (int)(r % Hp);
-    const long long b = r / Hp;
+  for (long long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+  // the position of the lane's first pixel by division, the seven that follow (16 positions further each) by stepping
+  long long m = blk * 512 + wave * 128 + l15;
+  int px = (int)(m % Wp);
+  long long b = m / Wp;
+  int py = (int)(b % Hp);
+  b /= Hp;
+  for (int tile = 0; tile < 8; ++tile, m += 16, px += 16) {
+    while (px >= Wp) {
+      px -= Wp;
+      if (++py == Hp) { py = 0; ++b; }
+    }
     const bool interior = (m < Mp && px < W && py < H);
     bf16x8 xhi[NKB], xlo[NKB];
 #pragma unroll
@@ -135,6 +145,7 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(int B, int H, int W
       }
     }
   }
+  }
   if (mode == UH_EPI_RAW_STATS) {
     // sum over the 16 pixels (lanes l15) of every group g, then over the four waves
 #pragma unroll
@@ -161,7 +172,12 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(int B, int H, int W
   }
 }
 
-extern "C" int uh_conv_first_parts(int B, int H, int W) { return (int)((uh_mp(B, H, W) + 511) / 512); }
+// workgroups of the forward launch = rows of its stat_partial: the weight fragments (32 loads and splits per lane) are
+// set up once per workgroup, so a workgroup takes several 512-position blocks
+extern "C" int uh_conv_first_parts(int B, int H, int W) {
+  const long long nblk = (uh_mp(B, H, W) + 511) / 512;
+  return (int)(nblk < 1024 ? nblk : 1024);
+}
 
 extern "C" int uh_conv_first_fwd(int B, int H, int W, int Cin, int Cout, const float* x, const float* w,
                                  const float* bias, int mode, const float* scale, const float* shift, void* out,
