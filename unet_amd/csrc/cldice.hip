@@ -283,19 +283,32 @@ __global__ __launch_bounds__(256) void skel_bwd_level_kernel(BwdArgs a) {
     pre_g1[k] = (a.ge1_in && i < N1 * N1 && g.in(y, x)) ? a.ge1_in[plane + (long long)y * a.W + x] : 0.f;
   }
   const float c4 = a.top ? a.coef[4] : 0.f, c5 = a.top ? a.coef[5] : 0.f;
-  for (int i = tid; i < N3 * N3; i += 256) {
+  // the two LDS images likewise: all loads first (from element 0 of the plane where the position is outside the image),
+  // then the stores; as a plain loop every iteration would wait for its own load before the next one is issued
+  constexpr int K3 = (N3 * N3 + 255) / 256;
+  float e1v[K3], ev[KA];
+#pragma unroll
+  for (int k = 0; k < K3; ++k) {
+    const int i = tid + 256 * k;
     const int y = y0 - 3 + i / N3, x = x0 - 3 + i % N3;
-    sE1[i] = g.in(y, x) ? ek1[y * a.W + x] : -INFINITY;
+    const bool ok = i < N3 * N3 && g.in(y, x);
+    const float v = ek1[ok ? y * a.W + x : 0];
+    e1v[k] = ok ? v : -INFINITY;
   }
-  for (int i = tid; i < N2 * N2; i += 256) {
+#pragma unroll
+  for (int k = 0; k < KA; ++k) {
+    const int i = tid + 256 * k;
     const int y = y0 - 2 + i / N2, x = x0 - 2 + i % N2;
-    float v = INFINITY;
-    if (g.in(y, x)) {
-      v = ek[y * a.W + x];
-      if (a.level0) v = clamp01(v);
-    }
-    sE[i] = v;
+    const bool ok = i < N2 * N2 && g.in(y, x);
+    const float v = ek[ok ? y * a.W + x : 0];
+    ev[k] = ok ? (a.level0 ? clamp01(v) : v) : INFINITY;
   }
+#pragma unroll
+  for (int k = 0; k < K3; ++k)
+    if (tid + 256 * k < N3 * N3) sE1[tid + 256 * k] = e1v[k];
+#pragma unroll
+  for (int k = 0; k < KA; ++k)
+    if (tid + 256 * k < N2 * N2) sE[tid + 256 * k] = ev[k];
   __syncthreads();
 
   // stage A: pointwise on core+2
