@@ -205,6 +205,10 @@ int uh_space_to_depth2_of(int B, int H, int W, int C, int bigH, int bigW, const 
                           void* out, int o_cstride, int o_coff, uh_stream s);
 int uh_depth_to_space2_to(int B, int H, int W, int C, int bigH, int bigW, const void* in, int i_cstride, int i_coff,
                           void* out, int o_cstride, int o_coff, uh_stream s);
+/* uh_depth_to_space2_to plus a tensor of the large geometry (pads zero): the gradient that comes back through a k2 s2
+ * convolution joined with the gradient of the skip connection taken before it (lunext.py:201-216 + autograd) */
+int uh_depth_to_space2_add(int B, int H, int W, int C, int bigH, int bigW, const void* in, int i_cstride, int i_coff,
+                           const void* add, int a_cstride, int a_coff, void* out, int o_cstride, int o_coff, uh_stream s);
 /* inverse scatter: out[(b,2y+t/2,2x+t%2)][c] = in[(b,y,x)][t*C + c], pads of out zero */
 int uh_depth_to_space2(int B, int H, int W, int C, const void* in, int i_cstride, int i_coff,
                        void* out, int o_cstride, int o_coff, uh_stream s);

@@ -855,6 +855,14 @@ def test_space_to_depth_of_odd_sizes(B, h, w, bigH, bigW, C):
     want[:, :, :2 * h, :2 * w] = x[:, :, :2 * h, :2 * w]      # the dropped row / column gets zeros
     assert torch.equal(back.to_nchw().cpu(), want)
     pads_are_zero(back)
+    extra = bf(torch.randn(B, C, bigH, bigW, generator=g))
+    ea = act_from(extra, cstride=2 * C, coff=C)
+    back.padded_rows()[:, :] = 3.0
+    call("uh_depth_to_space2_add", B, h, w, C, bigH, bigW, x4.ptr, x4.cstride, 0, ea.ptr, ea.cstride, ea.coff, back.ptr,
+         back.cstride, back.coff, S())
+    torch.cuda.synchronize()
+    assert torch.equal(back.to_nchw().cpu(), bf(want + extra))
+    pads_are_zero(back)
 
 
 # ---- AttentionGate kernels (lunext.py:76-122) ---------------------------------------------------------------------

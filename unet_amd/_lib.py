@@ -74,6 +74,7 @@ SIGNATURES = {
     "uh_dw_wgrad_finalize": (I, [P, I, I, I, P, P]),
     "uh_space_to_depth2_of": (I, [I, I, I, I, I, I, P, I, I, P, I, I, P]),
     "uh_depth_to_space2_to": (I, [I, I, I, I, I, I, P, I, I, P, I, I, P]),
+    "uh_depth_to_space2_add": (I, [I, I, I, I, I, I, P, I, I, P, I, I, P, I, I, P]),
     "uh_resize_bilinear_fwd": (I, [I, I, I, I, I, I, P, I, I, P, I, I, P]),
     "uh_resize_bilinear_bwd": (I, [I, I, I, I, I, I, P, I, I, P, I, I, P]),
     "uh_dwblock_bwd_parts": (I, [I, I, I, I]),

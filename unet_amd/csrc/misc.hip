@@ -141,9 +141,12 @@ extern "C" int uh_pack_weights_multi(const uh_pack_desc* descs_device, int count
 // (small position, tap); every row of the destination, pads included, is written exactly once.
 // The large geometry may also be (B, 2H+1, 2W+1): a k2 s2 convolution drops the last row / column of an odd-sized
 // input, and their gradient is zero (bigH, bigW are the large geometry's own H and W).
+// `add` (depth-to-space only): a tensor of the large geometry that is summed into the result (the gradient of a skip
+// connection joining the gradient that comes back through a k2 s2 convolution).
 template <bool TO_DEPTH>
 __global__ void s2d_kernel(int B, int H, int W, int C, int bigH, int bigW, const char* __restrict__ in, int i_cstride,
-                           int i_coff, char* __restrict__ out, int o_cstride, int o_coff) {
+                           int i_coff, char* __restrict__ out, int o_cstride, int o_coff,
+                           const char* __restrict__ add, int a_cstride, int a_coff) {
   const unsigned Wp = W + 1, Hp = H + 1, oWp = bigW + 1, oHp = bigH + 1;
   const unsigned cpr = C / 8;
   const unsigned total = (unsigned)B * Hp * Wp * cpr;                    // the host checks that this fits
@@ -174,6 +177,21 @@ __global__ void s2d_kernel(int B, int H, int W, int C, int bigH, int bigW, const
 #pragma unroll
         for (int t = 0; t < 4; ++t) v[t] = *(const U4*)(in + ((long long)ms * i_cstride + i_coff + t * C + cc * 8) * 2);
       }
+      if (add) {                                       // pads of `add` are zero, so the sum's pads stay zero
+        U4 av[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          av[t] = big_ok[t] ? *(const U4*)(add + (mb[t] * a_cstride + a_coff + cc * 8) * 2) : U4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          float f[8], h[8];
+          unpack8(v[t], f);
+          unpack8(av[t], h);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f[j] += h[j];
+          v[t] = pack8(f);
+        }
+      }
 #pragma unroll
       for (int t = 0; t < 4; ++t)
         if (big_ok[t]) *(U4*)(out + (mb[t] * o_cstride + o_coff + cc * 8) * 2) = v[t];
@@ -182,7 +200,8 @@ __global__ void s2d_kernel(int B, int H, int W, int C, int bigH, int bigW, const
 }
 
 static int s2d_launch(bool to_depth, int B, int H, int W, int C, int bigH, int bigW, const void* in, int i_cstride,
-                      int i_coff, void* out, int o_cstride, int o_coff, uh_stream s) {
+                      int i_coff, void* out, int o_cstride, int o_coff, uh_stream s, const void* add = nullptr,
+                      int a_cstride = 0, int a_coff = 0) {
   UH_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && in && out, "space/depth: bad arguments");
   UH_REQUIRE((bigH == 2 * H || bigH == 2 * H + 1) && (bigW == 2 * W || bigW == 2 * W + 1),
              "space/depth: large geometry %dx%d does not halve to %dx%d", bigH, bigW, H, W);
@@ -193,10 +212,10 @@ static int s2d_launch(bool to_depth, int B, int H, int W, int C, int bigH, int b
   if (blocks > 16384) blocks = 16384;
   if (to_depth)
     hipLaunchKernelGGL((s2d_kernel<true>), dim3(blocks), dim3(256), 0, (hipStream_t)s, B, H, W, C, bigH, bigW, (const char*)in,
-                       i_cstride, i_coff, (char*)out, o_cstride, o_coff);
+                       i_cstride, i_coff, (char*)out, o_cstride, o_coff, (const char*)nullptr, 0, 0);
   else
     hipLaunchKernelGGL((s2d_kernel<false>), dim3(blocks), dim3(256), 0, (hipStream_t)s, B, H, W, C, bigH, bigW, (const char*)in,
-                       i_cstride, i_coff, (char*)out, o_cstride, o_coff);
+                       i_cstride, i_coff, (char*)out, o_cstride, o_coff, (const char*)add, a_cstride, a_coff);
   return uh_check_launch("space/depth");
 }
 
@@ -215,6 +234,13 @@ extern "C" int uh_depth_to_space2(int B, int H, int W, int C, const void* in, in
 extern "C" int uh_depth_to_space2_to(int B, int H, int W, int C, int bigH, int bigW, const void* in, int i_cstride,
                                      int i_coff, void* out, int o_cstride, int o_coff, uh_stream s) {
   return s2d_launch(false, B, H, W, C, bigH, bigW, in, i_cstride, i_coff, out, o_cstride, o_coff, s);
+}
+extern "C" int uh_depth_to_space2_add(int B, int H, int W, int C, int bigH, int bigW, const void* in, int i_cstride,
+                                      int i_coff, const void* add, int a_cstride, int a_coff, void* out, int o_cstride,
+                                      int o_coff, uh_stream s) {
+  UH_REQUIRE(add && a_cstride % 8 == 0 && a_coff % 8 == 0, "depth_to_space2_add: bad `add` view");
+  return s2d_launch(false, B, H, W, C, bigH, bigW, in, i_cstride, i_coff, out, o_cstride, o_coff, s, add, a_cstride,
+                    a_coff);
 }
 
 // ---- Adam over one flat parameter buffer (torch.optim.Adam defaults, trainer/training_utils.py:107) ------------

@@ -191,7 +191,7 @@ class LUNeXtRun:
         return out
 
     @ranged(lambda l, *a: f"bwd/downconv{l + 1}")
-    def _down_backward(self, l, dy, grads):
+    def _down_backward(self, l, dy, grads, skip_grad):
         conv = getattr(self.m, f"downconv{l}")
         x4, K, cpi = self.saved[f"down{l}"]
         cin, cout = self.chans[l - 1], self.chans[l]
@@ -214,7 +214,9 @@ class LUNeXtRun:
              dx4.cstride, 0, None, None, None, None, self.masks[l].data_ptr(), s)
         B, H, W = self.geo[l - 1]
         dx = Ls.act(B, H, W, cpi)
-        call("uh_depth_to_space2_to", Bs, Hs, Ws, cpi, H, W, dx4.ptr, dx4.cstride, 0, dx.ptr, dx.cstride, dx.coff, s)
+        # joined with the gradient of the skip connection taken in front of the convolution
+        call("uh_depth_to_space2_add", Bs, Hs, Ws, cpi, H, W, dx4.ptr, dx4.cstride, 0, skip_grad.ptr, skip_grad.cstride,
+             skip_grad.coff, dx.ptr, dx.cstride, dx.coff, s)
         return dx
 
     # ------------------------------------------------------------------ transposed conv (lunext.py:161-179)
@@ -465,13 +467,7 @@ class LUNeXtRun:
             da = self._up_backward(k, dg, grads)
         da = self._dw_backward("conv5_1", self._dw_backward("conv5_2", da, grads), grads)
         for l in range(4, 0, -1):
-            dpool = self._down_backward(l, da, grads)
-            Bl, Hl, Wl = self.geo[l - 1]
-            C = self.cp[l - 1]
-            sg = skip_grads[l - 1]
-            tot = Ls.act(Bl, Hl, Wl, C)
-            call("uh_add", tot.Mp, C, dpool.ptr, dpool.cstride, dpool.coff, sg.ptr, sg.cstride, sg.coff, None, 0, 0,
-                 tot.ptr, tot.cstride, tot.coff, s)
+            tot = self._down_backward(l, da, grads, skip_grads[l - 1])
             da = self._dw_backward(f"conv{l}_1", self._dw_backward(f"conv{l}_2", tot, grads), grads)
         if self._side_used is not None:
             self._main.wait_stream(self._side_used)
