@@ -100,6 +100,12 @@ int uh_conv_gemm_bnbwd(int B, int H, int W, const void* a, int a_cstride, int a_
                        int N, void* out, int o_cstride, int o_coff, const uint8_t* rowmask, const void* y,
                        int y_cstride, int y_coff, const float* mean, const float* invstd, const float* scale,
                        const float* shift, float* stat_partial, uh_stream s);
+/* the same for a T = 1 GEMM: the input gradient of a k2 s2 transposed convolution (unet.py:132-164 + autograd), whose
+ * output is the gradient at the output of conv_up{k-1}_2 / conv5_2 */
+int uh_conv_gemm1_bnbwd(int B, int H, int W, const void* a, int a_cstride, int a_coff, int K, const void* w_packed,
+                       int N, void* out, int o_cstride, int o_coff, const uint8_t* rowmask, const void* y,
+                       int y_cstride, int y_coff, const float* mean, const float* invstd, const float* scale,
+                       const float* shift, float* stat_partial, uh_stream s);
 
 /* number of M tiles (= rows of stat_partial) uh_conv_gemm uses for this problem */
 int uh_conv_gemm_mtiles(int B, int H, int W, int N);

@@ -662,6 +662,38 @@ def test_conv_dgrad_with_batchnorm_backward_sums(B, H, W, Cin, Cout):
     assert ((got - sep).abs() <= 4e-3 * ref).all(), "fused sums against the separate pass"
 
 
+@pytest.mark.parametrize("B,H,W,K,N", [(2, 16, 16, 256, 128), (1, 8, 8, 128, 64), (3, 20, 20, 512, 256), (2, 5, 7, 64, 192)])
+def test_t1_gemm_with_batchnorm_backward_sums(B, H, W, K, N):
+    """uh_conv_gemm1_bnbwd: the output equals uh_conv_gemm(T = 1, UH_EPI_MASKED) bit for bit and the per-tile sums add up
+    to what uh_bn_relu_bwd_reduce gets from that output (fp32 accumulators against the bf16-rounded tensor)."""
+    g = torch.Generator().manual_seed(29)
+    a = act_from(bf(torch.randn(B, K, H, W, generator=g)))
+    wk = (torch.randn(N, K, generator=g) / (K ** 0.5)).to(torch.bfloat16).to(DEV)
+    y = (torch.randn(B, N, H, W, generator=g) * 2 + 0.3).half().float()
+    mean, invstd = torch.randn(N, generator=g) * 0.2, torch.rand(N, generator=g) + 0.5
+    gamma, beta = torch.randn(N, generator=g), torch.randn(N, generator=g) * 0.3
+    scale = gamma * invstd
+    st = [t.to(DEV) for t in (mean, invstd, scale, beta - mean * scale)]
+    ya = act_from(y, cstride=N + 64, coff=64, half=True)
+    mask = rowmask(B, H, W)
+    plain, fused = new_act(B, H, W, N, DEV), new_act(B, H, W, N, DEV)
+    call("uh_conv_gemm", B, H, W, a.ptr, a.cstride, a.coff, K, wk.data_ptr(), N, 1, _lib.EPI_MASKED, plain.ptr,
+         plain.cstride, plain.coff, None, None, None, None, mask.data_ptr(), S())
+    parts = lib.uh_conv_gemm_mtiles(B, H, W, N)
+    fp = torch.full((parts, 2, N), float("nan"), device=DEV)
+    call("uh_conv_gemm1_bnbwd", B, H, W, a.ptr, a.cstride, a.coff, K, wk.data_ptr(), N, fused.ptr, fused.cstride,
+         fused.coff, mask.data_ptr(), ya.ptr, ya.cstride, ya.coff, st[0].data_ptr(), st[1].data_ptr(),
+         st[2].data_ptr(), st[3].data_ptr(), fp.data_ptr(), S())
+    torch.cuda.synchronize()
+    assert torch.equal(plain.buf, fused.buf)
+    pads_are_zero(fused)
+    want, mag = _separate_sums(plain, ya, st)
+    got = fp.double().sum(0).cpu()
+    assert torch.isfinite(got).all()
+    xh_max = ((y - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1)).abs().max().item()
+    assert ((got - want).abs() <= 6e-3 * mag.max() * max(1.0, xh_max)).all()
+
+
 def _bn_bwd_setup(g, B, C, H, W):
     y = (torch.randn(B, C, H, W, generator=g) * 2 + 0.3).half().float()       # the layer's fp16 conv output
     mean, invstd = torch.randn(C, generator=g) * 0.2, torch.rand(C, generator=g) + 0.5

@@ -33,6 +33,7 @@ SIGNATURES = {
     "uh_conv_gemm_workspace": (Z, [I, I, I, I, I, I]),
     "uh_conv_gemm_ws": (I, [I, I, I, P, I, I, I, P, I, I, I, P, I, I, P, P, P, P, P, P, Z, P]),
     "uh_conv_gemm_bnbwd": (I, [I, I, I, P, I, I, I, P, I, P, I, I, P, P, I, I, P, P, P, P, P, P]),
+    "uh_conv_gemm1_bnbwd": (I, [I, I, I, P, I, I, I, P, I, P, I, I, P, P, I, I, P, P, P, P, P, P]),
     "uh_conv_gemm_mtiles": (I, [I, I, I, I]),
     "uh_conv_wgrad_splits": (I, [I, I, I, I, I, I]),
     "uh_conv_wgrad_workspace": (Z, [I, I, I, I, I, I]),

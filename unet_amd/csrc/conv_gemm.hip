@@ -649,7 +649,7 @@ __global__ __launch_bounds__(512) void conv_stream_kernel(GemmArgs p, BandSched 
 #pragma unroll
       for (int ii = 0; ii < 4; ++ii) af[ii] = *(const bf16x8*)(S + a_off + ii * 1024);
       if (c == 0) issue_flags(mt);
-      if (MODE == UH_EPI_RAW_STATS && c == 1 && pend_mt >= 0) {
+      if ((MODE == UH_EPI_RAW_STATS || MODE == UH_EPI_MASKED_BNBWD) && c == 1 && pend_mt >= 0) {
         band_flush_stats<BM, BN>(p, red, pend_mt, pend_nt, tid);
         pend_mt = -1;
       }
@@ -689,12 +689,12 @@ __global__ __launch_bounds__(512) void conv_stream_kernel(GemmArgs p, BandSched 
       stream_epilogue_convt<BM, BN>(p, acc, mt, nt, fw, wm, wn, l15, g);
     } else {
       band_epilogue<BM, BN, MODE>(p, acc, mt, nt, fw, wm, wn, l15, g, red);
-      if (MODE == UH_EPI_RAW_STATS) { pend_mt = mt; pend_nt = nt; }
+      if (MODE == UH_EPI_RAW_STATS || MODE == UH_EPI_MASKED_BNBWD) { pend_mt = mt; pend_nt = nt; }
     }
     u += u_step;
   }
   if (wave < 4) __builtin_amdgcn_s_barrier();   // match the second half's extra barrier
-  if (MODE == UH_EPI_RAW_STATS && pend_mt >= 0) {
+  if ((MODE == UH_EPI_RAW_STATS || MODE == UH_EPI_MASKED_BNBWD) && pend_mt >= 0) {
     __syncthreads();
     band_flush_stats<BM, BN>(p, red, pend_mt, pend_nt, tid);
   }
@@ -762,6 +762,7 @@ static void launch_stream(const GemmArgs& p, hipStream_t st) {
     case UH_EPI_RAW_STATS: launch_stream_mode<BM, BN, UH_EPI_RAW_STATS>(p, sc, st); break;
     case UH_EPI_AFFINE_RELU: launch_stream_mode<BM, BN, UH_EPI_AFFINE_RELU>(p, sc, st); break;
     case UH_EPI_MASKED: launch_stream_mode<BM, BN, UH_EPI_MASKED>(p, sc, st); break;
+    case UH_EPI_MASKED_BNBWD: launch_stream_mode<BM, BN, UH_EPI_MASKED_BNBWD>(p, sc, st); break;
     default: launch_stream_mode<BM, BN, UH_EPI_CONVT>(p, sc, st); break;
   }
 }
@@ -857,11 +858,11 @@ extern "C" int uh_conv_gemm_ws(int B, int H, int W, const void* a, int a_cstride
   return uh_check_launch("conv_gemm");
 }
 
-extern "C" int uh_conv_gemm_bnbwd(int B, int H, int W, const void* a, int a_cstride, int a_coff, int K,
-                                  const void* w_packed, int N, void* out, int o_cstride, int o_coff,
-                                  const uint8_t* rowmask, const void* y, int y_cstride, int y_coff, const float* mean,
-                                  const float* invstd, const float* scale, const float* shift, float* stat_partial,
-                                  uh_stream s) {
+static int gemm_bnbwd(int T, int B, int H, int W, const void* a, int a_cstride, int a_coff, int K,
+                      const void* w_packed, int N, void* out, int o_cstride, int o_coff,
+                      const uint8_t* rowmask, const void* y, int y_cstride, int y_coff, const float* mean,
+                      const float* invstd, const float* scale, const float* shift, float* stat_partial,
+                      uh_stream s) {
   UH_REQUIRE(B > 0 && H > 0 && W > 0, "conv_gemm_bnbwd: bad geometry B=%d H=%d W=%d", B, H, W);
   UH_REQUIRE(K > 0 && K % 64 == 0 && N > 0 && N % 64 == 0, "conv_gemm_bnbwd: K=%d N=%d must be multiples of 64", K, N);
   UH_REQUIRE(a && w_packed && out && rowmask && y && mean && invstd && scale && shift && stat_partial,
@@ -883,7 +884,7 @@ extern "C" int uh_conv_gemm_bnbwd(int B, int H, int W, const void* a, int a_cstr
   p.a_coff = a_coff;
   p.K = K;
   p.N = N;
-  p.T = 9;
+  p.T = T;
   p.KC = K / 64;
   p.Wp = W + 1;
   p.o_cstride = o_cstride;
@@ -898,9 +899,34 @@ extern "C" int uh_conv_gemm_bnbwd(int B, int H, int W, const void* a, int a_cstr
   p.bn_mean = mean;
   p.bn_invstd = invstd;
   hipStream_t st = (hipStream_t)s;
-  if (use_wide_m(N))
+  if (T == 1) {
+    UH_REQUIRE(uh_mp(B, H, W) < (1ll << 31) - 1024, "conv_gemm_bnbwd: too many rows");
+    if (use_wide_m(N))
+      launch_stream<512, 64>(p, st);
+    else
+      launch_stream<256, 128>(p, st);
+  } else if (use_wide_m(N)) {
     launch_band<512, 64>(p, nullptr, 0, st);
-  else
+  } else {
     launch_band<256, 128>(p, nullptr, 0, st);
+  }
   return uh_check_launch("conv_gemm_bnbwd");
+}
+
+extern "C" int uh_conv_gemm_bnbwd(int B, int H, int W, const void* a, int a_cstride, int a_coff, int K,
+                                  const void* w_packed, int N, void* out, int o_cstride, int o_coff,
+                                  const uint8_t* rowmask, const void* y, int y_cstride, int y_coff, const float* mean,
+                                  const float* invstd, const float* scale, const float* shift, float* stat_partial,
+                                  uh_stream s) {
+  return gemm_bnbwd(9, B, H, W, a, a_cstride, a_coff, K, w_packed, N, out, o_cstride, o_coff, rowmask, y, y_cstride,
+                    y_coff, mean, invstd, scale, shift, stat_partial, s);
+}
+
+extern "C" int uh_conv_gemm1_bnbwd(int B, int H, int W, const void* a, int a_cstride, int a_coff, int K,
+                                   const void* w_packed, int N, void* out, int o_cstride, int o_coff,
+                                   const uint8_t* rowmask, const void* y, int y_cstride, int y_coff, const float* mean,
+                                   const float* invstd, const float* scale, const float* shift, float* stat_partial,
+                                   uh_stream s) {
+  return gemm_bnbwd(1, B, H, W, a, a_cstride, a_coff, K, w_packed, N, out, o_cstride, o_coff, rowmask, y, y_cstride,
+                    y_coff, mean, invstd, scale, shift, stat_partial, s);
 }

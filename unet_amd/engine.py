@@ -44,6 +44,14 @@ def fuse_pool_stats():
 def fuse_pool_fwd():
     return os.environ.get("UNET_AMD_FUSE_POOL_FWD", "1") == "1"
 
+
+# UNET_AMD_FUSE_T1_STATS=1: the input gradient of a transposed convolution also takes the BatchNorm-backward sums of
+# the layer whose output gradient it writes (uh_conv_gemm1_bnbwd) instead of leaving them to uh_bn_relu_bwd_reduce.
+# Off by default, as UNET_AMD_FUSE_BN_BWD: measured on the training step the four passes it saves and the longer
+# epilogues cancel (13.72 against 13.74 ms).
+def fuse_t1_stats():
+    return os.environ.get("UNET_AMD_FUSE_T1_STATS", "0") == "1"
+
 _SIDE_STREAMS = {}
 
 
@@ -516,6 +524,22 @@ class UNetRun:
 
             def dgrad():
                 # input gradient: dx[m][ci] = sum_{t,co} d4[m][t*w+co] * W[ci][co][t]
+                nxt = f"conv_up{k - 1}_2" if k > 1 else "conv5_2"          # the layer whose output gradient this is
+                prev = self.recs[nxt]
+                if fuse_t1_stats() and prev.cout == cin:
+                    parts = _lib.lib.uh_conv_gemm_mtiles(Bs, Hs, Ws, cin)
+                    partial = L.f32(parts * 2 * cin)
+                    args = (Bs, Hs, Ws, d4.ptr, d4.cstride, d4.coff, 4 * w, wd.data_ptr(), cin, da.ptr, da.cstride,
+                            da.coff, self.masks[l + 1].data_ptr(), prev.y.ptr, prev.y.cstride, prev.y.coff,
+                            prev.mean.data_ptr(), prev.invstd.data_ptr(), prev.scale.data_ptr(),
+                            prev.shift.data_ptr(), partial.data_ptr(), s)
+                    if self.timer is None:
+                        call("uh_conv_gemm1_bnbwd", *args)
+                    else:
+                        with self.timer.launch("conv_gemm_t1", 2.0 * Bs * Hs * Ws * 4 * w * cin):
+                            call("uh_conv_gemm1_bnbwd", *args)
+                    self._fused_stats[nxt] = (partial, parts)
+                    return
                 self._gemm(Bs, Hs, Ws, d4.ptr, d4.cstride, d4.coff, 4 * w, wd.data_ptr(), cin, 1, EPI_MASKED,
                            da.ptr, da.cstride, da.coff, None, None, None, None, self.masks[l + 1].data_ptr(), s)
             side = self._side_stream()
