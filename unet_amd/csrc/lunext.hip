@@ -121,6 +121,11 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(long long Mp, int C, in
     float win[3][3][8];                 // [row slot][position][channel]
     dw_load3(xp - xrow, xs2, win[0]);
     dw_load3(xp, xs2, win[1]);
+    // the row after the next one is in flight while a row is computed: with two or three waves per SIMD one row of
+    // loads per thread does not cover the memory latency
+    U4 ahead[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ahead[k] = *(const U4*)(xp + xrow + (k - 1) * xs2);
 #pragma unroll
     for (int r = 0; r < DW_R; ++r) {
       if (r >= g.nr) continue;          // (not break: the loop must unroll so that the window slots are static)
@@ -128,7 +133,12 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(long long Mp, int C, in
       float(&top)[3][8] = win[r % 3];
       float(&mid)[3][8] = win[(r + 1) % 3];
       float(&bot)[3][8] = win[(r + 2) % 3];
-      dw_load3(xp + xrow, xs2, bot);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) unpack8(ahead[k], bot[k]);
+      if (r + 1 < g.nr) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) ahead[k] = *(const U4*)(xp + 2 * xrow + (k - 1) * xs2);
+      }
       U4 o = {0u, 0u, 0u, 0u};
       if (*mp) {
         float v[8];
