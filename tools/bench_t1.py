@@ -24,7 +24,9 @@ for k, (hs, w) in enumerate(((16, 512), (32, 256), (64, 128), (128, 64)), 1):
     Sp = lib.uh_conv_wgrad_splits(B, hs, hs, 4 * w, cin, 1)
     part = torch.empty(Sp * 4 * w * cin, device=DEV)
     wgr = lambda: call("uh_conv_wgrad", B, hs, hs, d4.ptr, d4.cstride, 0, 4 * w, a.ptr, a.cstride, 0, cin, 1, part.data_ptr(), S())
-    for nm, f in (("fwd", fwd), ("dgrad", dgr), ("wgrad", wgr)):
+    own = new_act(B, 2 * hs, 2 * hs, w, DEV)          # the same forward into a buffer of its own (contiguous rows)
+    fwc = lambda: call("uh_conv_gemm", B, hs, hs, a.ptr, a.cstride, 0, cin, wf.data_ptr(), 4 * w, 1, _lib.EPI_CONVT, own.ptr, own.cstride, 0, bias.data_ptr(), None, None, None, mask.data_ptr(), S())
+    for nm, f in (("fwd", fwd), ("fwd_c", fwc), ("dgrad", dgr), ("wgrad", wgr)):
         for _ in range(3): f()
         torch.cuda.synchronize()
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
@@ -35,5 +37,5 @@ for k, (hs, w) in enumerate(((16, 512), (32, 256), (64, 128), (128, 64)), 1):
         fl = 2.0 * B * hs * hs * cin * 4 * w
         by = Mp * (cin + 4 * w) * 2
         tot += ms
-        print(f"upconv{k} {nm:5s} M={Mp} K={cin if nm=='fwd' else 4*w} N={4*w if nm=='fwd' else cin}: {ms*1e3:7.1f} us {fl/ms/1e9:7.1f} TFLOP/s {by/ms/1e6:7.1f} GB/s", flush=True)
+        print(f"upconv{k} {nm:5s} M={Mp} K={cin if nm.startswith('fwd') else 4*w} N={4*w if nm.startswith('fwd') else cin}: {ms*1e3:7.1f} us {fl/ms/1e9:7.1f} TFLOP/s {by/ms/1e6:7.1f} GB/s", flush=True)
 print(f"total {tot*1e3:.1f} us")

@@ -487,7 +487,12 @@ struct StreamCfg {
   static constexpr int SG = AG + BG;
   static constexpr int NQ = (SG + 7) / 8;         // staging slots per wave
   static constexpr int STAGE = SG * 1024;
-  static constexpr int NSTAGE = 4;
+  // stage s + DIST is issued while stage s is consumed, into the buffer that held stage s - 2 (ring of DIST + 2).
+  // DIST = 3 (five stages, 126 KB at 256 x 128) was measured on the four transposed convolutions and their input
+  // gradients: no launch faster than with 2; these GEMMs are bound by the bytes staged per MFMA (24 KB for 128
+  // MFMAs), not by the latency of a stage.
+  static constexpr int DIST = 2;
+  static constexpr int NSTAGE = DIST + 2;
   static constexpr int FLAG_OFF = NSTAGE * STAGE;
   static constexpr int RED_OFF = FLAG_OFF + 8 * 256;
   static constexpr int LDS_BYTES = RED_OFF + WM * 2 * BN * 4;
@@ -509,36 +514,56 @@ __device__ __forceinline__ void stream_epilogue_convt(const GemmArgs& p, const f
   }
   const int Hp = p.H + 1, Wp = p.W + 1;
   const int oHp = 2 * p.H + 1, oWp = 2 * p.W + 1;
-  // position of the lane's first row, once per tile in 32-bit arithmetic (Mp < 2^31 is checked on the host), then
-  // stepped row by row: 64-bit divisions per row group cost more than the tile's MFMAs at K = 128
+  // Output row of input position (b, y, x) and this lane's tap: q = b*oHp*oWp + (2y + dy)*oWp + 2x + dx.  The lane's
+  // first row is decoded once per tile in 32-bit arithmetic (Mp < 2^31 and the output's row count are checked on the
+  // host); from there q is STEPPED with the position (+2 per x, two constants at the end of an image row / image), so a
+  // row costs a handful of integer instructions instead of a 64-bit multiply chain: at K = 128 the old form of this
+  // epilogue was 1085 instructions per wave and tile against 64 MFMAs.
+  const int dy = (otap >> 1) & 1, dx = otap & 1;
   const unsigned mrow0 = (unsigned)mt * BM + wm * 64 + g * 4;
   int x = (int)(mrow0 % (unsigned)Wp);
   const unsigned r = mrow0 / (unsigned)Wp;
   int y = (int)(r % (unsigned)Hp);
-  int b = (int)(r / (unsigned)Hp);
+  const unsigned b = r / (unsigned)Hp;
+  const unsigned row_step = 2u * oWp - 2u * Wp;                      // added on top of the +2 when x wraps
+  const unsigned img_step = (unsigned)oHp * oWp - 2u * Hp * oWp;     // added on top of that when y wraps
+  unsigned q = (b * oHp + 2u * y + dy) * oWp + 2u * x + dx;
+  const long long row_bytes = (long long)p.o_cstride * 2;
+  char* const obase = p.out + (long long)(p.o_coff + co) * 2;
+  const bool lane_ok = otap < 4;
+  const bool ragged = (long long)(mt + 1) * BM > p.Mp;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const long long m = (long long)mrow0 + i * 16 + e;
       const float f = (float)((fw[i] >> (8 * e)) & 0xffu);
       uint2 o;
       o.x = pack2((acc[i][0][e] + cb[0]) * f, (acc[i][1][e] + cb[1]) * f);
       o.y = pack2((acc[i][2][e] + cb[2]) * f, (acc[i][3][e] + cb[3]) * f);
-      const int Y = 2 * y + (otap >> 1), X = 2 * x + (otap & 1);
-      if (m < p.Mp && otap < 4 && Y < oHp && X < oWp) {
-        const long long om = ((long long)b * oHp + Y) * oWp + X;
-        *(uint2*)(p.out + (om * p.o_cstride + p.o_coff + co) * 2) = o;
-      }
+      // the pad row / column of the input maps to the output's pad row / column for dy = 0 / dx = 0 (zeros are
+      // stored there: f = 0) and past it for dy = 1 / dx = 1
+      bool ok = lane_ok && !(dy && y == p.H) && !(dx && x == p.W);
+      if (ragged) ok = ok && (long long)mrow0 + i * 16 + e < p.Mp;
+      if (ok) *(uint2*)(obase + (long long)q * row_bytes) = o;
+      q += 2;
       if (++x == Wp) {
         x = 0;
-        if (++y == Hp) { y = 0; ++b; }
+        q += row_step;
+        if (++y == Hp) {
+          y = 0;
+          q += img_step;
+        }
       }
     }
     x += 12;                                       // to the lane's next group of four rows, 16 rows on
+    q += 24;
     while (x >= Wp) {
       x -= Wp;
-      if (++y == Hp) { y = 0; ++b; }
+      q += row_step;
+      if (++y == Hp) {
+        y = 0;
+        q += img_step;
+      }
     }
   }
 }
@@ -617,16 +642,26 @@ __global__ __launch_bounds__(512) void conv_stream_kernel(GemmArgs p, BandSched 
     }
     stage_offsets();
   };
+  // all but this wave's `ahead` youngest stages have landed (a stage is NQ or NQ - 1 wave-instructions)
+  auto wait_stages = [&](int ahead) {
+    if (ahead <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (ahead == 1) {
+      if (has_last) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ - 1) : "memory");
+    } else {
+      if (has_last) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NQ) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NQ - 2) : "memory");
+    }
+  };
+  constexpr int DIST = C::DIST, NST = C::NSTAGE;
   stage_offsets();
   issue_stage(0, offA, offB);
-  if (total > 1) {
+  int issued = 1;                               // stages issued so far
+  for (; issued < DIST && issued < total; ++issued) {
     advance();
-    issue_stage(1, offA, offB);
-    if (has_last) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ) : "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ - 1) : "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    issue_stage(issued, offA, offB);
   }
+  wait_stages(issued - 1);                      // stage 0 has landed
   __builtin_amdgcn_s_barrier();
   if (wave >= 4) __builtin_amdgcn_s_barrier();  // the stagger
 
@@ -653,13 +688,14 @@ __global__ __launch_bounds__(512) void conv_stream_kernel(GemmArgs p, BandSched 
         band_flush_stats<BM, BN>(p, red, pend_mt, pend_nt, tid);
         pend_mt = -1;
       }
-      if (s + 2 < total) {
+      if (s + DIST < total) {
         advance();
-        issue_stage((buf + 2) & 3, offA, offB);
-        if (has_last) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ - 1) : "memory");
+        int nb = buf + DIST;
+        nb = nb >= NST ? nb - NST : nb;
+        issue_stage(nb, offA, offB);
+        wait_stages(DIST - 1);                  // stage s + 1 has landed; the younger ones stay in flight
       } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wait_stages(total - s - 2);             // the tail: whatever is younger than stage s + 1
       }
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
@@ -672,7 +708,7 @@ __global__ __launch_bounds__(512) void conv_stream_kernel(GemmArgs p, BandSched 
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
-      buf = (buf + 1) & 3;
+      buf = buf + 1 >= NST ? 0 : buf + 1;
     }
 
     uint32_t fw[4];
