@@ -12,6 +12,7 @@
 // along the channel axis, and fuses: bias, BatchNorm batch statistics (per-tile partial sums),
 // folded BatchNorm+ReLU (inference), pad-row zeroing, and the pixel-shuffle scatter of a
 // stride-2 transposed convolution.
+#include <cstdlib>
 #include "common.h"
 
 #include "conv_gemm.h"
@@ -22,8 +23,8 @@
 // Measured on MI355X the tile kernel above is bound by the global->LDS path (staging alone takes 80-97 %
 // of its time), and its per-tile prologue and LDS-transposing epilogue are exposed.  (Also measured, on this
 // kernel: with all loads removed its barrier/MFMA skeleton is only ~1.3x faster, with the MFMAs removed the
-// loads alone take ~70 % of the full time; 128-byte row pieces, 128x64 wave tiles with 512-row tiles, and
-// filter-row-innermost iteration order each left the speed unchanged within 5 %.)  This kernel
+// loads alone take ~70 % of the full time; 128-byte row pieces and 128x64 wave tiles with 512-row tiles each
+// left the speed unchanged within 5 %.)  This kernel
 //   * stages fewer bytes per FLOP: the three taps of one filter row (kx = 0,1,2) read the SAME activation
 //     rows shifted by one, so one staged band of BM+2 rows serves three taps; tiles are 256x128 or 512x64
 //     with eight waves of 64x64;
@@ -202,7 +203,10 @@ __device__ __forceinline__ void band_flush_stats(const GemmArgs& p, const float*
   }
 }
 
-template <int BM, int BN, int MODE>
+// KYIN: iteration order inside a unit.  false: filter row, then channel block.  true: channel block, then filter
+// row -- the three filter rows of a channel block read the same activation rows one image row apart in consecutive
+// stages, so two of the three reads hit in the XCD's L2 instead of going to memory again.
+template <int BM, int BN, int MODE, bool KYIN>
 __global__ __launch_bounds__(512) void conv_band_kernel(GemmArgs p, BandSched sc) {
   using C = BandCfg<BM, BN>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -297,19 +301,32 @@ __global__ __launch_bounds__(512) void conv_band_kernel(GemmArgs p, BandSched sc
   long long offA, offB;
   int u_n = u_first;
   int mt_n = u_n / ntn, nt_n = u_n % ntn;
-  int ky_n = it_first / KC, kc_n = it_first % KC;
+  int ky_n = KYIN ? it_first % 3 : it_first / KC, kc_n = KYIN ? it_first / 3 : it_first % KC;
   auto stage_offsets = [&]() {
     offA = ((long long)mt_n * BM + (long long)ky_n * p.Wp) * a_row_bytes + kc_n * 64;
     offB = (long long)nt_n * BN * b_row_bytes + ((long long)ky_n * 3 * p.K + kc_n * 32) * 2;
   };
+  auto next_unit = [&]() {
+    u_n += u_step;
+    mt_n = u_n / ntn;
+    nt_n = u_n - mt_n * ntn;
+  };
   auto advance = [&]() {
-    if (++kc_n == KC) {
-      kc_n = 0;
+    if (KYIN) {
       if (++ky_n == 3) {
         ky_n = 0;
-        u_n += u_step;
-        mt_n = u_n / ntn;
-        nt_n = u_n - mt_n * ntn;
+        if (++kc_n == KC) {
+          kc_n = 0;
+          next_unit();
+        }
+      }
+    } else {
+      if (++kc_n == KC) {
+        kc_n = 0;
+        if (++ky_n == 3) {
+          ky_n = 0;
+          next_unit();
+        }
       }
     }
     stage_offsets();
@@ -742,11 +759,28 @@ static size_t band_workspace_bytes(long long Mp, int N, int K) {
   return (size_t)2 * band_workgroups(units, 3 * (K / 32)) * BM * BN * sizeof(float);
 }
 
+// Largest K whose launches walk a unit channel block first (UNET_AMD_BAND_KYIN_MAXK; default: every K; 0: none).
+// Measured at B = 32, 256^2: the L2's memory-side reads of a K = 64 launch drop from three times the activation
+// bytes to 1.04 times, the launch takes the same time alone (its re-reads were served by the Infinity Cache) and
+// the training step gains 0 - 0.1 ms from the bandwidth left to the kernels running beside it.
+static int band_kyin_maxk() {
+  static const int v = [] {
+    const char* e = getenv("UNET_AMD_BAND_KYIN_MAXK");
+    return e ? atoi(e) : 1 << 30;
+  }();
+  return v;
+}
+
 template <int BM, int BN, int MODE>
 static void launch_band_mode(const GemmArgs& p, const BandSched& sc, hipStream_t st) {
   using C = BandCfg<BM, BN>;
-  uh_set_max_lds((const void*)conv_band_kernel<BM, BN, MODE>, C::LDS_BYTES);
-  hipLaunchKernelGGL((conv_band_kernel<BM, BN, MODE>), dim3(sc.G), dim3(512), C::LDS_BYTES, st, p, sc);
+  if (p.K <= band_kyin_maxk()) {
+    uh_set_max_lds((const void*)conv_band_kernel<BM, BN, MODE, true>, C::LDS_BYTES);
+    hipLaunchKernelGGL((conv_band_kernel<BM, BN, MODE, true>), dim3(sc.G), dim3(512), C::LDS_BYTES, st, p, sc);
+  } else {
+    uh_set_max_lds((const void*)conv_band_kernel<BM, BN, MODE, false>, C::LDS_BYTES);
+    hipLaunchKernelGGL((conv_band_kernel<BM, BN, MODE, false>), dim3(sc.G), dim3(512), C::LDS_BYTES, st, p, sc);
+  }
   if (!sc.aligned)
     hipLaunchKernelGGL((conv_band_fixup_kernel<BM, BN, MODE>), dim3(sc.G - 1), dim3(512), 0, st, p, sc);
 }
@@ -761,9 +795,6 @@ static void launch_band(const GemmArgs& p, void* ws, size_t ws_bytes, hipStream_
   sc.G = band_workgroups(units, sc.niter);
   sc.ws = (float*)ws;
   sc.upx = (int)((units + 7) / 8);
-  // (Iteration order inside a unit is filter row, then channel block.  The other order nearly halves the L2's
-  // memory-side reads for K >= 256 -- the next filter row's band still hits in L2 -- but was not faster inside
-  // the training step, and choosing the order at run time cost 25 % through the extra scalar code in the loop.)
   // even cuts need the workspace and cost a second launch plus ~2 x 128 KB of traffic per workgroup, and the
   // workgroups of a thinly populated last round run faster than those of a full one: measured, even cuts win
   // from about a third of the CU-time idle (137x4 and 37x8 tiles on 256 CUs), not at a fifth (529x2 tiles)
