@@ -54,16 +54,21 @@ struct BandCfg {
   static constexpr int NSTAGE = 3;
   static constexpr int FLAG_OFF = NSTAGE * STAGE;             // 8 waves x 64 dwords of row flags
   static constexpr int RED_OFF = FLAG_OFF + 8 * 256;          // float[WM][2][BN]
-  static constexpr int LDS_BYTES = RED_OFF + WM * 2 * BN * 4;
+  static constexpr int COEF_OFF = RED_OFF + WM * 2 * BN * 4;  // 8 waves x float[2][64]: per-channel epilogue constants
+  static constexpr int LDS_BYTES = COEF_OFF + 8 * 512;
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
 // Epilogue of one unit, straight from the accumulators: lane (l15, g) of wave (wm, wn) holds rows
 // wm*64 + i*16 + g*4 + e and the 4 adjacent channels wn*64 + l15*4 + j of the tile; fw[i] = the four row
 // flags of rows i*16 + g*4 .. +3.  RAW_STATS leaves the wave's channel sums in red[wm][2][BN].
+// coef: the wave's float[2][64] in LDS holding bias (or scale) and shift of its 64 columns, brought in by DMA during
+// the tile (a global load here would be waited for with vmcnt(0), which also drains the staging DMAs of the next
+// tile's first stages that are in flight by now); nullptr: read them from global memory.
 template <int BM, int BN, int MODE>
 __device__ __forceinline__ void band_epilogue(const GemmArgs& p, const f32x4 (&acc)[4][4], int mt, int nt,
-                                              const uint32_t (&fw)[4], int wm, int wn, int l15, int g, float* red) {
+                                              const uint32_t (&fw)[4], int wm, int wn, int l15, int g, float* red,
+                                              const float* coef = nullptr) {
   // While a workgroup is here none of its waves issues MFMAs, and at K = 64 this is a quarter of a tile's life,
   // so the arithmetic is laid out for the packed fp32 instructions: values are handled as PAIRS OF ROWS (e, e+1),
   // which are adjacent registers of one accumulator, so no register moves are needed to form the operands.
@@ -74,11 +79,12 @@ __device__ __forceinline__ void band_epilogue(const GemmArgs& p, const f32x4 (&a
 #pragma unroll
   for (int j = 0; j < 4; ++j) { cb[j] = f32x2{0.f, 0.f}; csc[j] = f32x2{1.f, 1.f}; }
   if (MODE == UH_EPI_AFFINE_RELU) {
-    const f32x4 a4 = *(const f32x4*)(p.scale + n0 + ncol), b4 = *(const f32x4*)(p.shift + n0 + ncol);
+    const f32x4 a4 = coef ? *(const f32x4*)(coef + l15 * 4) : *(const f32x4*)(p.scale + n0 + ncol);
+    const f32x4 b4 = coef ? *(const f32x4*)(coef + 64 + l15 * 4) : *(const f32x4*)(p.shift + n0 + ncol);
 #pragma unroll
     for (int j = 0; j < 4; ++j) { csc[j] = f32x2{a4[j], a4[j]}; cb[j] = f32x2{b4[j], b4[j]}; }
   } else if (p.bias) {
-    const f32x4 b4 = *(const f32x4*)(p.bias + n0 + ncol);
+    const f32x4 b4 = coef ? *(const f32x4*)(coef + l15 * 4) : *(const f32x4*)(p.bias + n0 + ncol);
 #pragma unroll
     for (int j = 0; j < 4; ++j) cb[j] = f32x2{b4[j], b4[j]};
   }
@@ -277,6 +283,18 @@ __global__ __launch_bounds__(512) void conv_band_kernel(GemmArgs p, BandSched sc
                                      (UH_LDS void*)(smem + C::FLAG_OFF + wave * 256), 4, 0, 0);
   };
 
+  // per-channel epilogue constants of this wave's 64 columns, one float per lane: bias (or scale), then shift
+  auto issue_coef = [&](int nt) {
+    const float* first = (MODE == UH_EPI_AFFINE_RELU) ? p.scale : p.bias;
+    const long long col = (long long)nt * BN + wn * 64 + lane;
+    if (first)
+      __builtin_amdgcn_global_load_lds((const UH_GLOBAL void*)(first + col),
+                                       (UH_LDS void*)(smem + C::COEF_OFF + wave * 512), 4, 0, 0);
+    if (MODE == UH_EPI_AFFINE_RELU)
+      __builtin_amdgcn_global_load_lds((const UH_GLOBAL void*)(p.shift + col),
+                                       (UH_LDS void*)(smem + C::COEF_OFF + wave * 512 + 256), 4, 0, 0);
+  };
+
   // ---- fragment read offsets (bytes inside a stage) -----------------------------------------------------
   int a_off[3];
 #pragma unroll
@@ -286,6 +304,7 @@ __global__ __launch_bounds__(512) void conv_band_kernel(GemmArgs p, BandSched sc
   }
   const int b_off = C::AG * 1024 + (wn * 64 + l15) * 64 + ((g ^ ((l15 >> 1) & 2)) << 4);
   float* red = (float*)(smem + C::RED_OFF);
+  const float* coef = (const float*)(smem + C::COEF_OFF + wave * 512);
 
   // ---- main loop ---------------------------------------------------------------------------------------------
   // The (unit, iteration) pairs of this workgroup form one stream of stages s = 0 .. total-1; a stage is one
@@ -371,7 +390,10 @@ __global__ __launch_bounds__(512) void conv_band_kernel(GemmArgs p, BandSched sc
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) af[ii] = *(const bf16x8*)(S + a_off[kx] + ii * 1024);
         if (kx == 0) {
-          if (c == 0 && full) issue_flags(mt);
+          if (c == 0 && full) {
+            issue_flags(mt);
+            issue_coef(nt);
+          }
           if (s + 1 < total) {
             issue(4, buf1, offA, offB);
             if (has_slot5) issue(5, buf1, offA, offB);
@@ -414,7 +436,7 @@ __global__ __launch_bounds__(512) void conv_band_kernel(GemmArgs p, BandSched sc
       uint32_t fw[4];
 #pragma unroll
       for (int ii = 0; ii < 4; ++ii) fw[ii] = *(const uint32_t*)(smem + C::FLAG_OFF + wave * 256 + (ii * 4 + g) * 4);
-      band_epilogue<BM, BN, MODE>(p, acc, mt, nt, fw, wm, wn, l15, g, red);
+      band_epilogue<BM, BN, MODE>(p, acc, mt, nt, fw, wm, wn, l15, g, red, coef);
       if (MODE == UH_EPI_RAW_STATS || MODE == UH_EPI_MASKED_BNBWD) { pend_mt = mt; pend_nt = nt; }
     } else {
       // a piece of a unit: park the accumulators for conv_band_fixup_kernel
