@@ -235,26 +235,49 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_col_kernel(WgradArgs p) {
       asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_addr), "v"(src) : "memory");
     }
   };
-  auto where = [&](long long it, int& row, long long& mb) {
-    const int strip = (int)(it / p.total_rows);
-    row = (int)(it - (long long)strip * p.total_rows);
-    mb = (long long)row * p.Wp + strip * 64;
+  // The common case, the next image row of the same strip (dY + the one new band, into slot (rot + 2) & 3 counted from
+  // the rotation the ring will then have), with nothing but pointer additions per stage: a wave's two dY groups
+  // (wave, wave + 4) and two or three band groups (wave, wave + 4, and 8 for wave 0) sit at fixed offsets from the
+  // stage's first pixel, and the pointers to that pixel advance by one image row.  (Measured with cycle stamps: the
+  // general form above, with its 64-bit products and the division that finds a stage's strip, took as long per
+  // stage as the stage's 72 MFMAs.)
+  const int dy_rb = p.dy_cstride * 2, a_rb = p.a_cstride * 2;
+  const int dy_g0 = wave * 8 * dy_rb, dy_g1 = (wave + 4) * 8 * dy_rb;
+  const int a_g0 = wave * 8 * a_rb, a_g1 = (wave + 4) * 8 * a_rb, a_g2 = 8 * 8 * a_rb;
+  const long long dy_step = (long long)p.Wp * dy_rb, a_step = (long long)p.Wp * a_rb;
+  const char* a_new = a_lane + (long long)(p.Wp - 1) * a_rb;       // band 2 of a stage starts Wp - 1 pixels behind it
+  auto dma = [&](const char* src, int dst) {
+    const uint32_t lds_addr = (uint32_t)(uintptr_t)(UH_LDS char*)(smem + dst);
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_addr), "v"(src) : "memory");
+  };
+  auto issue_next_row = [&](const char* dyp, const char* ap, int db_n, int rot_n) {
+    const int dyb = db_n * C::DY_BYTES + wave * 1024;
+    const int bnd = C::BAND_OFF + ((rot_n + 2) & 3) * C::BAND_BYTES + wave * 1024;
+    dma(dyp + dy_g0, dyb);
+    dma(dyp + dy_g1, dyb + 4096);
+    dma(ap + a_g0, bnd);
+    dma(ap + a_g1, bnd + 4096);
+    if (wave == 0) dma(ap + a_g2, bnd + 8192);
   };
 
   if (ms < me) {
-    int row, rot = 0, db = 0;
-    long long mb;
-    where(ms, row, mb);
+    int rot = 0, db = 0;
+    int strip = (int)(ms / p.total_rows);
+    int row = (int)(ms - (long long)strip * p.total_rows);
+    long long mb = (long long)row * p.Wp + strip * 64;
+    const char* dyp = dy_lane + mb * dy_rb;                         // this stage's first pixel, this lane's piece
+    const char* ap = a_new + mb * a_rb;
     issue(mb, 0, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (long long it = ms; it < me; ++it) {
-      int row_n = 0;
-      long long mb_n = 0;
       const bool more = it + 1 < me;
-      if (more) where(it + 1, row_n, mb_n);
-      const bool follows = more && row_n == row + 1;         // the next stage is the next image row of this strip
-      if (follows) issue(mb_n, db ^ 1, (rot + 1) & 3, 2);
+      const bool follows = more && row + 1 < p.total_rows;   // the next stage is the next image row of this strip
+      if (follows) {
+        dyp += dy_step;
+        ap += a_step;
+        issue_next_row(dyp, ap, db ^ 1, (rot + 1) & 3);
+      }
       const char* dyb = smem + db * C::DY_BYTES;
       int boff[3];
 #pragma unroll
@@ -295,15 +318,20 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_col_kernel(WgradArgs p) {
       }
       if (follows) {
         rot = (rot + 1) & 3;
+        ++row;
       } else if (more) {                                     // a new strip: nothing of this stage is reused
         __syncthreads();
         rot = 0;
-        issue(mb_n, db ^ 1, 0, 0);
+        row = 0;
+        ++strip;
+        mb = (long long)strip * 64;
+        dyp = dy_lane + mb * dy_rb;
+        ap = a_new + mb * a_rb;
+        issue(mb, db ^ 1, 0, 0);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       db ^= 1;
-      row = row_n;
     }
   }
 
