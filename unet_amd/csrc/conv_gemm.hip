@@ -534,7 +534,8 @@ struct StreamCfg {
   static constexpr int NSTAGE = DIST + 2;
   static constexpr int FLAG_OFF = NSTAGE * STAGE;
   static constexpr int RED_OFF = FLAG_OFF + 8 * 256;
-  static constexpr int LDS_BYTES = RED_OFF + WM * 2 * BN * 4;
+  static constexpr int COEF_OFF = RED_OFF + WM * 2 * BN * 4;  // 8 waves x float[2][64], as in BandCfg
+  static constexpr int LDS_BYTES = COEF_OFF + 8 * 512;
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
@@ -542,14 +543,16 @@ struct StreamCfg {
 // (b, y, x) goes to output position (b, 2y + tap/2, 2x + tap%2), channel co, of the (B, 2H, 2W) output geometry.
 template <int BM, int BN>
 __device__ __forceinline__ void stream_epilogue_convt(const GemmArgs& p, const f32x4 (&acc)[4][4], int mt, int nt,
-                                                      const uint32_t (&fw)[4], int wm, int wn, int l15, int g) {
+                                                      const uint32_t (&fw)[4], int wm, int wn, int l15, int g,
+                                                      const float* coef) {
   const int n = nt * BN + wn * 64 + l15 * 4;
   const int otap = n / p.Cout;                     // >= 4: zero-padded weight rows (N > 4*Cout)
   const int co = n - otap * p.Cout;
   float cb[4] = {0.f, 0.f, 0.f, 0.f};
-  if (p.bias && otap < 4) {
+  if (p.bias) {                                    // the bias of the wave's 64 columns, brought into LDS during the tile
+    const f32x4 b4 = *(const f32x4*)(coef + l15 * 4);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) cb[j] = p.bias[co + j];
+    for (int j = 0; j < 4; ++j) cb[j] = b4[j];
   }
   const int Hp = p.H + 1, Wp = p.W + 1;
   const int oHp = 2 * p.H + 1, oWp = 2 * p.W + 1;
@@ -662,6 +665,29 @@ __global__ __launch_bounds__(512) void conv_stream_kernel(GemmArgs p, BandSched 
                                      (UH_LDS void*)(smem + C::FLAG_OFF + wave * 256), 4, 0, 0);
   };
 
+  // per-channel epilogue constants of this wave's 64 columns, one float per lane (see band_epilogue): bias (or scale),
+  // then shift; for a transposed convolution column n carries the bias of output channel n % Cout
+  auto issue_coef = [&](int nt) {
+    const int n = nt * BN + wn * 64 + lane;
+    if (MODE == UH_EPI_CONVT) {
+      if (p.bias) {
+        const int otap = n / p.Cout;
+        const int co = otap < 4 ? n - otap * p.Cout : 0;         // columns of zero-padded weight rows are never stored
+        __builtin_amdgcn_global_load_lds((const UH_GLOBAL void*)(p.bias + co),
+                                         (UH_LDS void*)(smem + C::COEF_OFF + wave * 512), 4, 0, 0);
+      }
+    } else {
+      const float* first = (MODE == UH_EPI_AFFINE_RELU) ? p.scale : p.bias;
+      if (first)
+        __builtin_amdgcn_global_load_lds((const UH_GLOBAL void*)(first + n),
+                                         (UH_LDS void*)(smem + C::COEF_OFF + wave * 512), 4, 0, 0);
+      if (MODE == UH_EPI_AFFINE_RELU)
+        __builtin_amdgcn_global_load_lds((const UH_GLOBAL void*)(p.shift + n),
+                                         (UH_LDS void*)(smem + C::COEF_OFF + wave * 512 + 256), 4, 0, 0);
+    }
+  };
+  const float* coef = (const float*)(smem + C::COEF_OFF + wave * 512);
+
   // ---- fragment read offsets (bytes inside a stage) -----------------------------------------------------
   const int a_off = (wm * 64 + l15) * 64 + ((g ^ ((l15 >> 1) & 2)) << 4);
   const int b_off = C::AG * 1024 + (wn * 64 + l15) * 64 + ((g ^ ((l15 >> 1) & 2)) << 4);
@@ -722,7 +748,10 @@ __global__ __launch_bounds__(512) void conv_stream_kernel(GemmArgs p, BandSched 
       for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(S + b_off + j * 1024);
 #pragma unroll
       for (int ii = 0; ii < 4; ++ii) af[ii] = *(const bf16x8*)(S + a_off + ii * 1024);
-      if (c == 0) issue_flags(mt);
+      if (c == 0) {
+        issue_flags(mt);
+        issue_coef(nt);
+      }
       if ((MODE == UH_EPI_RAW_STATS || MODE == UH_EPI_MASKED_BNBWD) && c == 1 && pend_mt >= 0) {
         band_flush_stats<BM, BN>(p, red, pend_mt, pend_nt, tid);
         pend_mt = -1;
@@ -761,9 +790,9 @@ __global__ __launch_bounds__(512) void conv_stream_kernel(GemmArgs p, BandSched 
           for (int e = 0; e < 4; ++e)
             if ((long long)mt * BM + wm * 64 + ii * 16 + g * 4 + e >= p.Mp) fw[ii] &= ~(0xffu << (8 * e));
       }
-      stream_epilogue_convt<BM, BN>(p, acc, mt, nt, fw, wm, wn, l15, g);
+      stream_epilogue_convt<BM, BN>(p, acc, mt, nt, fw, wm, wn, l15, g, coef);
     } else {
-      band_epilogue<BM, BN, MODE>(p, acc, mt, nt, fw, wm, wn, l15, g, red);
+      band_epilogue<BM, BN, MODE>(p, acc, mt, nt, fw, wm, wn, l15, g, red, coef);
       if (MODE == UH_EPI_RAW_STATS || MODE == UH_EPI_MASKED_BNBWD) { pend_mt = mt; pend_nt = nt; }
     }
     u += u_step;
