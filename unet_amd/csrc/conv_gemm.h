@@ -24,8 +24,8 @@ struct GemmArgs {
   const float* bn_invstd;
 };
 
-// How the work of one launch is cut.  A "unit" is one BM x BN output tile (unit u: M tile u / ntn, N tile
-// u % ntn) and takes niter = 3*K/32 iterations; the launch is the sequence of all (unit, iteration) pairs and
+// How the work of one launch is cut.  A "unit" is one BM x BN output tile (numbered as band_unit() below says) and
+// takes niter = 3*K/32 iterations; the launch is the sequence of all (unit, iteration) pairs and
 // workgroup position p takes a list of them.  With `aligned` a workgroup takes whole units: the 8 XCDs split
 // the units into 8 contiguous ranges, and inside a range workgroup j takes units j, j + G/8, j + 2G/8, ... so that
 // the workgroups that run at the same time on one XCD work on NEIGHBOURING tiles (the bands of neighbouring M
@@ -35,11 +35,27 @@ struct GemmArgs {
 // covers only part of a unit leaves its accumulators in `ws` (slot 2p: the piece starts inside the unit,
 // slot 2p+1: it ends inside), and conv_band_fixup_kernel sums the pieces of every cut unit in position order
 // and runs the epilogue -- a second launch instead of workgroups waiting for each other.
+// Unit order.  nmajor = 0: unit u is M tile u / ntn, N tile u % ntn -- the N tiles of an M tile follow each other, an
+// activation tile is fetched once and the whole weight matrix passes through every XCD's L2 again and again: right
+// while the matrix stays resident there.  nmajor = 1: N tile u / ntm, M tile u % ntm -- an XCD's contiguous range of
+// units then has one or two N tiles, whose weight slice stays in its L2, and the (small, deep-layer) activations are
+// re-read per N tile instead: for the layers whose weights are several times the 4 MB of an L2.
 struct BandSched {
   int ntm, ntn, niter, G, aligned;
   int upx;        // aligned: units per XCD range
+  int nmajor;
   float* ws;
 };
+
+__device__ __forceinline__ void band_unit(const BandSched& sc, int u, int& mt, int& nt) {
+  if (sc.nmajor) {
+    nt = u / sc.ntm;
+    mt = u - nt * sc.ntm;
+  } else {
+    mt = u / sc.ntn;
+    nt = u - mt * sc.ntn;
+  }
+}
 
 __device__ __forceinline__ long long band_start(const BandSched& sc, int pos) {
   const long long units = (long long)sc.ntm * sc.ntn;

@@ -32,6 +32,12 @@ def fuse_bn_bwd(lvl=0):
 
 
 
+# UNET_AMD_DGRAD_CUT_LEVELS: resolution levels (0 = full size) whose 3x3 input gradients are cut evenly over the CUs
+# (workspace + a second kernel for the cut tiles) instead of taking whole tiles per workgroup.
+def dgrad_cut_levels():
+    return os.environ.get("UNET_AMD_DGRAD_CUT_LEVELS", "")
+
+
 # UNET_AMD_FUSE_POOL_STATS=0: the BatchNorm-backward sums of conv{l}_2 and conv_up4_2 are taken in a pass of their own
 # (uh_bn_relu_bwd_reduce).  By default the bandwidth-bound kernels that write those layers' output gradients
 # (uh_maxpool2_bwd_bnstat, uh_head_bwd_bnstat) take them on the way: one read of the gradient and one launch less each.
@@ -425,7 +431,7 @@ class UNetRun:
                 return out
             self._gemm(B, H, W, dy.ptr, dy.cstride, dy.coff, C, wd.data_ptr(), cin, 9, EPI_MASKED,
                        out.ptr, out.cstride, out.coff, None, None, None, None, self.masks[lvl].data_ptr(), s,
-                       whole_tiles=True)
+                       whole_tiles=str(lvl) not in dgrad_cut_levels())
             return out
         if first:
             ev = torch.cuda.Event()
