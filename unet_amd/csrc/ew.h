@@ -75,35 +75,12 @@ __device__ __forceinline__ void reduce_partials(const float* __restrict__ partia
 #pragma unroll
   for (int k = 0; k < NSTAT; ++k) s[k] = 0.0;
   if (c0 + c8 < C) {
-    // eight rows are fetched before any is added (in row order, so the sums do not depend on the batching): added as
-    // they arrive, every row costs a full memory latency -- 33 in a row for the 4161 tiles of a 256^2 layer
-    constexpr int NB = 8;
-    const float* col = partial + c0 + c8;
-    int p = slot;
-    for (; p + (NB - 1) * 128 < P; p += NB * 128) {
-      float v[NB][NSTAT];
+    // (Measured: fetching eight rows before adding any leaves the kernel's time unchanged, so the chain of loads is
+    // not what it waits for.  The launches that take 20-28 us instead of 5 are those right behind a layer that wrote
+    // hundreds of MB, with 8 rows per thread as with 33.)
+    for (int p = slot; p < P; p += 128) {
 #pragma unroll
-      for (int b = 0; b < NB; ++b)
-#pragma unroll
-        for (int k = 0; k < NSTAT; ++k) v[b][k] = col[((long long)(p + b * 128) * NSTAT + k) * C];
-#pragma unroll
-      for (int b = 0; b < NB; ++b)
-#pragma unroll
-        for (int k = 0; k < NSTAT; ++k) s[k] += (double)v[b][k];
-    }
-    if (p < P) {                                   // the last, partial batch: loads from a valid row, zeros added
-      float v[NB][NSTAT];
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const int pb = p + b * 128;
-        const int row = pb < P ? pb : slot;
-#pragma unroll
-        for (int k = 0; k < NSTAT; ++k) v[b][k] = col[((long long)row * NSTAT + k) * C];
-      }
-#pragma unroll
-      for (int b = 0; b < NB; ++b)
-#pragma unroll
-        for (int k = 0; k < NSTAT; ++k) s[k] += (p + b * 128 < P) ? (double)v[b][k] : 0.0;
+      for (int k = 0; k < NSTAT; ++k) s[k] += (double)partial[((long long)p * NSTAT + k) * C + c0 + c8];
     }
   }
 #pragma unroll
