@@ -212,7 +212,7 @@ __device__ __forceinline__ void band_flush_stats(const GemmArgs& p, const float*
 // KYIN: iteration order inside a unit.  false: filter row, then channel block.  true: channel block, then filter
 // row -- the three filter rows of a channel block read the same activation rows one image row apart in consecutive
 // stages, so two of the three reads hit in the XCD's L2 instead of going to memory again.
-template <int BM, int BN, int MODE, bool KYIN>
+template <int BM, int BN, int MODE, bool KYIN, bool NMAJOR>
 __global__ __launch_bounds__(512) void conv_band_kernel(GemmArgs p, BandSched sc) {
   using C = BandCfg<BM, BN>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(512) void conv_band_kernel(GemmArgs p, BandSched sc
   long long offA, offB;
   int u_n = u_first;
   int mt_n, nt_n;
-  band_unit(sc, u_n, mt_n, nt_n);
+  band_unit<NMAJOR>(sc, u_n, mt_n, nt_n);
   int ky_n = KYIN ? it_first % 3 : it_first / KC, kc_n = KYIN ? it_first / 3 : it_first % KC;
   auto stage_offsets = [&]() {
     offA = ((long long)mt_n * BM + (long long)ky_n * p.Wp) * a_row_bytes + kc_n * 64;
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(512) void conv_band_kernel(GemmArgs p, BandSched sc
   };
   auto next_unit = [&]() {
     u_n += u_step;
-    band_unit(sc, u_n, mt_n, nt_n);
+    band_unit<NMAJOR>(sc, u_n, mt_n, nt_n);
   };
   auto advance = [&]() {
     if (KYIN) {
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(512) void conv_band_kernel(GemmArgs p, BandSched sc
     const int cnt = min(niter - it_a, total - s);
     const bool full = (it_a == 0 && cnt == niter);
     int mt, nt;
-    band_unit(sc, u, mt, nt);
+    band_unit<NMAJOR>(sc, u, mt, nt);
     f32x4 acc[4][4];
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii)
@@ -489,7 +489,8 @@ __global__ __launch_bounds__(512) void conv_band_fixup_kernel(GemmArgs p, BandSc
       for (int j = 0; j < 4; ++j) acc[ii][j] += slot[(ii * 4 + j) * 512];
   }
   int mt, nt;
-  band_unit(sc, (int)u, mt, nt);
+  if (sc.nmajor) band_unit<true>(sc, (int)u, mt, nt);
+  else band_unit<false>(sc, (int)u, mt, nt);
   uint32_t fw[4];
   const long long mask_last_dword = (p.Mp - 1) >> 2;
 #pragma unroll
@@ -699,7 +700,7 @@ __global__ __launch_bounds__(512) void conv_stream_kernel(GemmArgs p, BandSched 
   int u_n = u_first, kc_n = 0;
   auto stage_offsets = [&]() {
     int mt_n, nt_n;
-    band_unit(sc, u_n, mt_n, nt_n);
+    band_unit<false>(sc, u_n, mt_n, nt_n);
     offA = (long long)mt_n * BM * a_row_bytes + kc_n * 64;
     offB = (long long)nt_n * BN * b_row_bytes + kc_n * 64;
   };
@@ -739,7 +740,7 @@ __global__ __launch_bounds__(512) void conv_stream_kernel(GemmArgs p, BandSched 
   bf16x8 af[4], bfr[4];
   while (s < total) {
     int mt, nt;
-    band_unit(sc, u, mt, nt);
+    band_unit<false>(sc, u, mt, nt);
     f32x4 acc[4][4];
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii)
@@ -838,12 +839,17 @@ static bool weights_outgrow_l2(long long weight_bytes) {
 template <int BM, int BN, int MODE>
 static void launch_band_mode(const GemmArgs& p, const BandSched& sc, hipStream_t st) {
   using C = BandCfg<BM, BN>;
-  if (p.K <= band_kyin_maxk()) {
-    uh_set_max_lds((const void*)conv_band_kernel<BM, BN, MODE, true>, C::LDS_BYTES);
-    hipLaunchKernelGGL((conv_band_kernel<BM, BN, MODE, true>), dim3(sc.G), dim3(512), C::LDS_BYTES, st, p, sc);
+  auto go = [&](auto kernel) {
+    uh_set_max_lds((const void*)kernel, C::LDS_BYTES);
+    hipLaunchKernelGGL(kernel, dim3(sc.G), dim3(512), C::LDS_BYTES, st, p, sc);
+  };
+  const bool kyin = p.K <= band_kyin_maxk();
+  if (sc.nmajor) {                                 // (only cut launches, which only the forward modes have)
+    if (kyin) go(conv_band_kernel<BM, BN, MODE, true, true>);
+    else go(conv_band_kernel<BM, BN, MODE, false, true>);
   } else {
-    uh_set_max_lds((const void*)conv_band_kernel<BM, BN, MODE, false>, C::LDS_BYTES);
-    hipLaunchKernelGGL((conv_band_kernel<BM, BN, MODE, false>), dim3(sc.G), dim3(512), C::LDS_BYTES, st, p, sc);
+    if (kyin) go(conv_band_kernel<BM, BN, MODE, true, false>);
+    else go(conv_band_kernel<BM, BN, MODE, false, false>);
   }
   if (!sc.aligned)
     hipLaunchKernelGGL((conv_band_fixup_kernel<BM, BN, MODE>), dim3(sc.G - 1), dim3(512), 0, st, p, sc);
