@@ -54,21 +54,46 @@ struct BandCfg {
   static constexpr int NSTAGE = 3;
   static constexpr int FLAG_OFF = NSTAGE * STAGE;             // 8 waves x 64 dwords of row flags
   static constexpr int RED_OFF = FLAG_OFF + 8 * 256;          // float[WM][2][BN]
-  static constexpr int COEF_OFF = RED_OFF + WM * 2 * BN * 4;  // 8 waves x float[2][64]: per-channel epilogue constants
-  static constexpr int LDS_BYTES = COEF_OFF + 8 * 512;
+  static constexpr int COEF_OFF = RED_OFF + WM * 2 * BN * 4;  // 8 waves x float[4][64]: per-channel epilogue constants
+  static constexpr int LDS_BYTES = COEF_OFF + 8 * 1024;
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
 // Epilogue of one unit, straight from the accumulators: lane (l15, g) of wave (wm, wn) holds rows
 // wm*64 + i*16 + g*4 + e and the 4 adjacent channels wn*64 + l15*4 + j of the tile; fw[i] = the four row
 // flags of rows i*16 + g*4 .. +3.  RAW_STATS leaves the wave's channel sums in red[wm][2][BN].
-// coef: the wave's float[2][64] in LDS holding bias (or scale) and shift of its 64 columns, brought in by DMA during
+// UH_EPI_MASKED_BNBWD: the consuming layer's fp16 conv output at the lane's rows i_lo*16 .. i_hi*16 (x 4 channels) of
+// the tile, for the epilogue's second pass.  Issued at the top of the epilogue: its stores, which are younger, stay in
+// flight across the wait for these loads (the memory counter retires in order), and they cover the loads' latency.
+// (Issued during the tile's last stage instead, the compiler -- which does not see the main loop's hand-written
+// waits -- protects the registers with vmcnt(0) waits of its own all over the loop.)
+template <int BM, int BN>
+__device__ __forceinline__ void band_load_y(const GemmArgs& p, int mt, int nt, int wm, int wn, int l15, int g, int i_lo,
+                                            int i_hi, uint2 (&yraw)[4][4]) {
+  const long long mrow0 = (long long)mt * BM + wm * 64 + g * 4;
+  const bool ragged = (long long)(mt + 1) * BM > p.Mp;
+  const long long y_row_bytes = (long long)p.y_cstride * 2;
+  const char* yrow = p.ybn + (long long)(p.y_coff + nt * BN + wn * 64 + l15 * 4) * 2;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (i < i_lo || i >= i_hi) continue;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      long long m = mrow0 + i * 16 + e;
+      if (ragged && m >= p.Mp) m = p.Mp - 1;                // masked out in the epilogue; only the address has to be valid
+      yraw[i][e] = *(const uint2*)(yrow + m * y_row_bytes);
+    }
+  }
+}
+
+// coef: the wave's float[4][64] in LDS holding bias (or scale) and shift of its 64 columns -- UH_EPI_MASKED_BNBWD: the
+// consuming BatchNorm's scale, shift, mean, 1/std -- brought in by DMA during
 // the tile (a global load here would be waited for with vmcnt(0), which also drains the staging DMAs of the next
 // tile's first stages that are in flight by now); nullptr: read them from global memory.
 template <int BM, int BN, int MODE>
 __device__ __forceinline__ void band_epilogue(const GemmArgs& p, const f32x4 (&acc)[4][4], int mt, int nt,
                                               const uint32_t (&fw)[4], int wm, int wn, int l15, int g, float* red,
-                                              const float* coef = nullptr) {
+                                              const float* coef, const uint2 (&yraw)[4][4]) {
   // While a workgroup is here none of its waves issues MFMAs, and at K = 64 this is a quarter of a tile's life,
   // so the arithmetic is laid out for the packed fp32 instructions: values are handled as PAIRS OF ROWS (e, e+1),
   // which are adjacent registers of one accumulator, so no register moves are needed to form the operands.
@@ -95,19 +120,6 @@ __device__ __forceinline__ void band_epilogue(const GemmArgs& p, const f32x4 (&a
   f32x2 s1[4], s2[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) { s1[j] = f32x2{0.f, 0.f}; s2[j] = f32x2{0.f, 0.f}; }
-  uint2 yraw[4][4];                                         // UH_EPI_MASKED_BNBWD: y of the lane's 16 rows x 4 channels
-  if (MODE == UH_EPI_MASKED_BNBWD) {
-    const long long y_row_bytes = (long long)p.y_cstride * 2;
-    const char* yrow = p.ybn + (long long)(p.y_coff + n0 + ncol) * 2;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        long long m = mrow0 + i * 16 + e;
-        if (ragged && m >= p.Mp) m = p.Mp - 1;              // masked out below; only the address has to be valid
-        yraw[i][e] = *(const uint2*)(yrow + m * y_row_bytes);
-      }
-  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     uint32_t fl = fw[i];
@@ -153,8 +165,10 @@ __device__ __forceinline__ void band_epilogue(const GemmArgs& p, const f32x4 (&a
   if (MODE == UH_EPI_MASKED_BNBWD) {
     // Second pass over the accumulators, after all stores of the tile have been issued (they cover the latency of
     // the y loads): d = out * (y*scale + shift > 0); sums of d and of d * xhat per column.
-    const f32x4 sc4 = *(const f32x4*)(p.scale + n0 + ncol), sh4 = *(const f32x4*)(p.shift + n0 + ncol);
-    const f32x4 mu4 = *(const f32x4*)(p.bn_mean + n0 + ncol), is4 = *(const f32x4*)(p.bn_invstd + n0 + ncol);
+    const f32x4 sc4 = coef ? *(const f32x4*)(coef + l15 * 4) : *(const f32x4*)(p.scale + n0 + ncol);
+    const f32x4 sh4 = coef ? *(const f32x4*)(coef + 64 + l15 * 4) : *(const f32x4*)(p.shift + n0 + ncol);
+    const f32x4 mu4 = coef ? *(const f32x4*)(coef + 128 + l15 * 4) : *(const f32x4*)(p.bn_mean + n0 + ncol);
+    const f32x4 is4 = coef ? *(const f32x4*)(coef + 192 + l15 * 4) : *(const f32x4*)(p.bn_invstd + n0 + ncol);
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -285,14 +299,21 @@ __global__ __launch_bounds__(512) void conv_band_kernel(GemmArgs p, BandSched sc
 
   // per-channel epilogue constants of this wave's 64 columns, one float per lane: bias (or scale), then shift
   auto issue_coef = [&](int nt) {
-    const float* first = (MODE == UH_EPI_AFFINE_RELU) ? p.scale : p.bias;
+    const bool bn = MODE == UH_EPI_AFFINE_RELU || MODE == UH_EPI_MASKED_BNBWD;
+    const float* first = bn ? p.scale : p.bias;
     const long long col = (long long)nt * BN + wn * 64 + lane;
     if (first)
       __builtin_amdgcn_global_load_lds((const UH_GLOBAL void*)(first + col),
-                                       (UH_LDS void*)(smem + C::COEF_OFF + wave * 512), 4, 0, 0);
-    if (MODE == UH_EPI_AFFINE_RELU)
+                                       (UH_LDS void*)(smem + C::COEF_OFF + wave * 1024), 4, 0, 0);
+    if (bn)
       __builtin_amdgcn_global_load_lds((const UH_GLOBAL void*)(p.shift + col),
-                                       (UH_LDS void*)(smem + C::COEF_OFF + wave * 512 + 256), 4, 0, 0);
+                                       (UH_LDS void*)(smem + C::COEF_OFF + wave * 1024 + 256), 4, 0, 0);
+    if (MODE == UH_EPI_MASKED_BNBWD) {
+      __builtin_amdgcn_global_load_lds((const UH_GLOBAL void*)(p.bn_mean + col),
+                                       (UH_LDS void*)(smem + C::COEF_OFF + wave * 1024 + 512), 4, 0, 0);
+      __builtin_amdgcn_global_load_lds((const UH_GLOBAL void*)(p.bn_invstd + col),
+                                       (UH_LDS void*)(smem + C::COEF_OFF + wave * 1024 + 768), 4, 0, 0);
+    }
   };
 
   // ---- fragment read offsets (bytes inside a stage) -----------------------------------------------------
@@ -304,7 +325,7 @@ __global__ __launch_bounds__(512) void conv_band_kernel(GemmArgs p, BandSched sc
   }
   const int b_off = C::AG * 1024 + (wn * 64 + l15) * 64 + ((g ^ ((l15 >> 1) & 2)) << 4);
   float* red = (float*)(smem + C::RED_OFF);
-  const float* coef = (const float*)(smem + C::COEF_OFF + wave * 512);
+  const float* coef = (const float*)(smem + C::COEF_OFF + wave * 1024);
 
   // ---- main loop ---------------------------------------------------------------------------------------------
   // The (unit, iteration) pairs of this workgroup form one stream of stages s = 0 .. total-1; a stage is one
@@ -437,7 +458,9 @@ __global__ __launch_bounds__(512) void conv_band_kernel(GemmArgs p, BandSched sc
       uint32_t fw[4];
 #pragma unroll
       for (int ii = 0; ii < 4; ++ii) fw[ii] = *(const uint32_t*)(smem + C::FLAG_OFF + wave * 256 + (ii * 4 + g) * 4);
-      band_epilogue<BM, BN, MODE>(p, acc, mt, nt, fw, wm, wn, l15, g, red, coef);
+      uint2 yraw[4][4];
+      if (MODE == UH_EPI_MASKED_BNBWD) band_load_y<BM, BN>(p, mt, nt, wm, wn, l15, g, 0, 4, yraw);
+      band_epilogue<BM, BN, MODE>(p, acc, mt, nt, fw, wm, wn, l15, g, red, coef, yraw);
       if (MODE == UH_EPI_RAW_STATS || MODE == UH_EPI_MASKED_BNBWD) { pend_mt = mt; pend_nt = nt; }
     } else {
       // a piece of a unit: park the accumulators for conv_band_fixup_kernel
@@ -499,7 +522,9 @@ __global__ __launch_bounds__(512) void conv_band_fixup_kernel(GemmArgs p, BandSc
     if (d > mask_last_dword) d = mask_last_dword;
     fw[ii] = *(const uint32_t*)(p.rowmask + 4 * d);
   }
-  band_epilogue<BM, BN, MODE>(p, acc, mt, nt, fw, wm, wn, l15, g, red);
+  uint2 yraw[4][4];
+  if (MODE == UH_EPI_MASKED_BNBWD) band_load_y<BM, BN>(p, mt, nt, wm, wn, l15, g, 0, 4, yraw);
+  band_epilogue<BM, BN, MODE>(p, acc, mt, nt, fw, wm, wn, l15, g, red, nullptr, yraw);
   if (MODE == UH_EPI_RAW_STATS || MODE == UH_EPI_MASKED_BNBWD) {
     __syncthreads();
     band_flush_stats<BM, BN>(p, red, mt, nt, tid);
@@ -537,8 +562,8 @@ struct StreamCfg {
   static constexpr int NSTAGE = DIST + 2;
   static constexpr int FLAG_OFF = NSTAGE * STAGE;
   static constexpr int RED_OFF = FLAG_OFF + 8 * 256;
-  static constexpr int COEF_OFF = RED_OFF + WM * 2 * BN * 4;  // 8 waves x float[2][64], as in BandCfg
-  static constexpr int LDS_BYTES = COEF_OFF + 8 * 512;
+  static constexpr int COEF_OFF = RED_OFF + WM * 2 * BN * 4;  // 8 waves x float[4][64], as in BandCfg
+  static constexpr int LDS_BYTES = COEF_OFF + 8 * 1024;
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
@@ -677,19 +702,26 @@ __global__ __launch_bounds__(512) void conv_stream_kernel(GemmArgs p, BandSched 
         const int otap = n / p.Cout;
         const int co = otap < 4 ? n - otap * p.Cout : 0;         // columns of zero-padded weight rows are never stored
         __builtin_amdgcn_global_load_lds((const UH_GLOBAL void*)(p.bias + co),
-                                         (UH_LDS void*)(smem + C::COEF_OFF + wave * 512), 4, 0, 0);
+                                         (UH_LDS void*)(smem + C::COEF_OFF + wave * 1024), 4, 0, 0);
       }
     } else {
-      const float* first = (MODE == UH_EPI_AFFINE_RELU) ? p.scale : p.bias;
+      const bool bn = MODE == UH_EPI_AFFINE_RELU || MODE == UH_EPI_MASKED_BNBWD;
+      const float* first = bn ? p.scale : p.bias;
       if (first)
         __builtin_amdgcn_global_load_lds((const UH_GLOBAL void*)(first + n),
-                                         (UH_LDS void*)(smem + C::COEF_OFF + wave * 512), 4, 0, 0);
-      if (MODE == UH_EPI_AFFINE_RELU)
+                                         (UH_LDS void*)(smem + C::COEF_OFF + wave * 1024), 4, 0, 0);
+      if (bn)
         __builtin_amdgcn_global_load_lds((const UH_GLOBAL void*)(p.shift + n),
-                                         (UH_LDS void*)(smem + C::COEF_OFF + wave * 512 + 256), 4, 0, 0);
+                                         (UH_LDS void*)(smem + C::COEF_OFF + wave * 1024 + 256), 4, 0, 0);
+      if (MODE == UH_EPI_MASKED_BNBWD) {
+        __builtin_amdgcn_global_load_lds((const UH_GLOBAL void*)(p.bn_mean + n),
+                                         (UH_LDS void*)(smem + C::COEF_OFF + wave * 1024 + 512), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((const UH_GLOBAL void*)(p.bn_invstd + n),
+                                         (UH_LDS void*)(smem + C::COEF_OFF + wave * 1024 + 768), 4, 0, 0);
+      }
     }
   };
-  const float* coef = (const float*)(smem + C::COEF_OFF + wave * 512);
+  const float* coef = (const float*)(smem + C::COEF_OFF + wave * 1024);
 
   // ---- fragment read offsets (bytes inside a stage) -----------------------------------------------------
   const int a_off = (wm * 64 + l15) * 64 + ((g ^ ((l15 >> 1) & 2)) << 4);
@@ -797,7 +829,9 @@ __global__ __launch_bounds__(512) void conv_stream_kernel(GemmArgs p, BandSched 
       }
       stream_epilogue_convt<BM, BN>(p, acc, mt, nt, fw, wm, wn, l15, g, coef);
     } else {
-      band_epilogue<BM, BN, MODE>(p, acc, mt, nt, fw, wm, wn, l15, g, red, coef);
+      uint2 yraw[4][4];
+      if (MODE == UH_EPI_MASKED_BNBWD) band_load_y<BM, BN>(p, mt, nt, wm, wn, l15, g, 0, 4, yraw);
+      band_epilogue<BM, BN, MODE>(p, acc, mt, nt, fw, wm, wn, l15, g, red, coef, yraw);
       if (MODE == UH_EPI_RAW_STATS || MODE == UH_EPI_MASKED_BNBWD) { pend_mt = mt; pend_nt = nt; }
     }
     u += u_step;
