@@ -124,9 +124,11 @@ def test_conv_gemm_raw_stats(B, H, W, Cin, Cout):
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 32, 32, 64, 128), (1, 16, 16, 128, 64), (2, 48, 48, 64, 256),
-                                            (1, 16, 16, 64, 64), (3, 40, 40, 128, 256), (2, 16, 16, 192, 512)])
+                                            (1, 16, 16, 64, 64), (3, 40, 40, 128, 256), (2, 16, 16, 192, 512),
+                                            (2, 16, 16, 512, 512), (1, 32, 32, 1024, 256), (3, 16, 16, 512, 1024)])
 def test_conv_gemm_even_cuts(B, H, W, Cin, Cout):
-    """uh_conv_gemm_ws: workgroups that own pieces of tiles + the fix-up launch give the whole-tile result."""
+    """uh_conv_gemm_ws: workgroups that own pieces of tiles + the fix-up launch give the whole-tile result.  (The
+    last three cases have weights of more than 3 MB: their cut launches number the tiles N tile first.)"""
     g = torch.Generator().manual_seed(B * 77 + H + Cin)
     x = bf(torch.randn(B, Cin, H, W, generator=g))
     w = bf(torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5))
