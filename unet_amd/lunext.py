@@ -197,11 +197,11 @@ class LUNeXtRun:
         cin, cout = self.chans[l - 1], self.chans[l]
         Bs, Hs, Ws = self.geo[l]
         s, Ls = self._sh, self.lease
-        grads[f"downconv{l}.bias"] = self._colsum(dy, cout)
         S = L.uh_conv_wgrad_splits(Bs, Hs, Ws, cout, K, 1)
         part = Ls.f32(S * cout * K)
         dw = torch.empty_like(conv.weight)
         with self._side() as s2:
+            grads[f"downconv{l}.bias"] = self._colsum(dy, cout, s2)
             call("uh_conv_wgrad", Bs, Hs, Ws, dy.ptr, dy.cstride, dy.coff, cout, x4.ptr, x4.cstride, 0, K, 1,
                  part.data_ptr(), s2)
             call("uh_wgrad_reduce_strided", part.data_ptr(), S, cout * K, cout, 4, cin, K, cpi, cin * 4, 1, 4,
@@ -257,7 +257,8 @@ class LUNeXtRun:
             call("uh_resize_bilinear_bwd", B, 2 * Hs, 2 * Ws, H, W, cpo, dup.ptr, dup.cstride, dup.coff, raw.ptr,
                  raw.cstride, raw.coff, s)
             dup = raw
-        grads[f"upconv{k}.bias"] = self._colsum(dup, cpo)[:cout]           # a view of a tensor made for this gradient
+        with self._side() as s2:
+            grads[f"upconv{k}.bias"] = self._colsum(dup, cpo, s2)[:cout]   # a view of a tensor made for this gradient
         d4 = Ls.act(Bs, Hs, Ws, N, tag=f"up{k}.d4")
         call("uh_space_to_depth2", Bs, Hs, Ws, cpo, dup.ptr, dup.cstride, dup.coff, d4.ptr, d4.cstride, 0, s)
         S = L.uh_conv_wgrad_splits(Bs, Hs, Ws, N, cin, 1)
@@ -305,8 +306,9 @@ class LUNeXtRun:
         self._zero_used += n
         return out
 
-    def _colsum(self, a, C):
-        s, Ls = self._sh, self.lease
+    def _colsum(self, a, C, s=None):
+        """column sums of `a` (a bias gradient) on stream s (default: the main stream)"""
+        s, Ls = (self._sh if s is None else s), self.lease
         parts = L.uh_colsum_parts(a.Mp, C)
         cp = Ls.f32(parts * C)
         call("uh_colsum", a.Mp, C, a.ptr, a.cstride, a.coff, cp.data_ptr(), s)
@@ -375,25 +377,26 @@ class LUNeXtRun:
         dz, dxd = Ls.act(B, H, W, 3 * C), Ls.act(B, H, W, C)
         call("uh_gate_bwd", g.Mp, C, dout.ptr, dout.cstride, dout.coff, z.ptr, z.cstride, 0, x.ptr, x.cstride, x.coff,
              mask.data_ptr(), dz.ptr, dz.cstride, 0, dxd.ptr, dxd.cstride, dxd.coff, s)
-        db = self._colsum(dz, 3 * C)
-        for j, nm in enumerate(("sigmoid_conv", "tanh_conv", "combine_conv")):
-            grads[pre + nm + ".bias"] = db[j * C:(j + 1) * C]
-        # weight gradients: [dW1; dW2] = dz[:, :2C]^T g,  dW3 = dz[:, 2C:]^T (g + x)
+        # bias and weight gradients only read dz, g and g + x: on the second stream, beside the input gradients below
+        # (weight gradients: [dW1; dW2] = dz[:, :2C]^T g,  dW3 = dz[:, 2C:]^T (g + x))
         S = L.uh_conv_wgrad_splits(B, H, W, 2 * C, C, 1)
         part = Ls.f32(S * 2 * C * C)
-        call("uh_conv_wgrad", B, H, W, dz.ptr, dz.cstride, 0, 2 * C, g.ptr, g.cstride, g.coff, C, 1, part.data_ptr(), s)
-        for j, nm in enumerate(("sigmoid_conv", "tanh_conv")):
-            dw = torch.empty(C, C, 1, 1, dtype=torch.float32, device=self.device)
-            call("uh_wgrad_reduce_strided", part.data_ptr() + j * C * C * 4, S, 2 * C * C, C, 1, C, C, 0, C, 0, 1,
-                 dw.data_ptr(), 0, s)
-            grads[pre + nm + ".weight"] = dw
         S3 = L.uh_conv_wgrad_splits(B, H, W, C, C, 1)
         part3 = Ls.f32(S3 * C * C)
-        call("uh_conv_wgrad", B, H, W, dz.ptr, dz.cstride, 2 * C, C, ssum.ptr, ssum.cstride, ssum.coff, C, 1,
-             part3.data_ptr(), s)
-        dw3 = torch.empty(C, C, 1, 1, dtype=torch.float32, device=self.device)
-        call("uh_wgrad_reduce", part3.data_ptr(), S3, C, 1, C, C, 0, C, 0, 1, dw3.data_ptr(), 0, s)
-        grads[pre + "combine_conv.weight"] = dw3
+        dws = [torch.empty(C, C, 1, 1, dtype=torch.float32, device=self.device) for _ in range(3)]
+        with self._side() as s2:
+            db = self._colsum(dz, 3 * C, s2)
+            call("uh_conv_wgrad", B, H, W, dz.ptr, dz.cstride, 0, 2 * C, g.ptr, g.cstride, g.coff, C, 1,
+                 part.data_ptr(), s2)
+            for j in range(2):
+                call("uh_wgrad_reduce_strided", part.data_ptr() + j * C * C * 4, S, 2 * C * C, C, 1, C, C, 0, C, 0, 1,
+                     dws[j].data_ptr(), 0, s2)
+            call("uh_conv_wgrad", B, H, W, dz.ptr, dz.cstride, 2 * C, C, ssum.ptr, ssum.cstride, ssum.coff, C, 1,
+                 part3.data_ptr(), s2)
+            call("uh_wgrad_reduce", part3.data_ptr(), S3, C, 1, C, C, 0, C, 0, 1, dws[2].data_ptr(), 0, s2)
+        for j, nm in enumerate(("sigmoid_conv", "tanh_conv", "combine_conv")):
+            grads[pre + nm + ".bias"] = db[j * C:(j + 1) * C]
+            grads[pre + nm + ".weight"] = dws[j]
         # input gradients: dg = sum_j dz_j W_j (one GEMM over K = 3C),  ds = dz_3 W_3,  dx = dout*a + ds
         wd = self.wb[f"att{k}.wd"]
         dg = Ls.act(B, H, W, C)
