@@ -402,13 +402,20 @@ class LUNeXtRun:
         dg = Ls.act(B, H, W, C)
         call("uh_conv_gemm", B, H, W, dz.ptr, dz.cstride, 0, 3 * C, wd.data_ptr(), C, 1, EPI_MASKED, dg.ptr,
              dg.cstride, dg.coff, None, None, None, None, mask.data_ptr(), s)
+        # dx is the gradient of the skip connection: nothing needs it before the encoder's backward reaches this level,
+        # so its two launches go to the second stream too (backward() makes the main stream wait for `ready` there)
         wd3 = self.wb[f"att{k}.wd3"]
         ds = Ls.act(B, H, W, C)
-        call("uh_conv_gemm", B, H, W, dz.ptr, dz.cstride, 2 * C, C, wd3.data_ptr(), C, 1, EPI_MASKED, ds.ptr,
-             ds.cstride, ds.coff, None, None, None, None, mask.data_ptr(), s)
         dx = Ls.act(B, H, W, C)
-        call("uh_add", g.Mp, C, dxd.ptr, dxd.cstride, dxd.coff, ds.ptr, ds.cstride, ds.coff, None, 0, 0, dx.ptr,
-             dx.cstride, dx.coff, s)
+        with self._side() as s2:
+            call("uh_conv_gemm", B, H, W, dz.ptr, dz.cstride, 2 * C, C, wd3.data_ptr(), C, 1, EPI_MASKED, ds.ptr,
+                 ds.cstride, ds.coff, None, None, None, None, mask.data_ptr(), s2)
+            call("uh_add", g.Mp, C, dxd.ptr, dxd.cstride, dxd.coff, ds.ptr, ds.cstride, ds.coff, None, 0, 0, dx.ptr,
+                 dx.cstride, dx.coff, s2)
+        if self._two_streams:
+            ready = torch.cuda.Event()
+            ready.record(self._side_st)
+            self._skip_ready[l] = ready
         return dg, dx
 
     # ------------------------------------------------------------------ whole network
@@ -462,6 +469,7 @@ class LUNeXtRun:
         grads["final_conv.weight"] = hw[:, :cin].reshape(oc, cin, 1, 1)
         grads["final_conv.bias"] = hw[:, 8]
         skip_grads = [None] * 4
+        self._skip_ready = {}
         for k in range(4, 0, -1):
             l = 4 - k
             da = self._dw_backward(f"conv_up{k}_1", self._dw_backward(f"conv_up{k}_2", da, grads), grads)
@@ -470,6 +478,8 @@ class LUNeXtRun:
             da = self._up_backward(k, dg, grads)
         da = self._dw_backward("conv5_1", self._dw_backward("conv5_2", da, grads), grads)
         for l in range(4, 0, -1):
+            if (l - 1) in self._skip_ready:
+                self._main.wait_event(self._skip_ready[l - 1])
             tot = self._down_backward(l, da, grads, skip_grads[l - 1])
             da = self._dw_backward(f"conv{l}_1", self._dw_backward(f"conv{l}_2", tot, grads), grads)
         if self._side_used is not None:
