@@ -71,11 +71,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs p) {
 
   // staging: LDS row r keeps source chunk c at position c ^ (((r>>1)&3)<<1); an 8-row group
   // always starts at a multiple of 8, so the swizzle depends on the lane only.
+  // A DMA's source is a wave-uniform base (scalar registers, scalar arithmetic) plus this lane's fixed 32-bit offset
+  // inside a group of eight rows.
   const int lrow = lane >> 3;
   const int src_chunk = (lane & 7) ^ (((lane >> 4) & 3) << 1);
   const long long dy_row_bytes = (long long)p.dy_cstride * 2, a_row_bytes = (long long)p.a_cstride * 2;
-  const char* dy_lane = p.dY + (long long)lrow * dy_row_bytes + (long long)(p.dy_coff + n0) * 2 + src_chunk * 16;
-  const char* a_lane = p.A + (long long)lrow * a_row_bytes + (long long)(p.a_coff + k0) * 2 + src_chunk * 16;
+  const uint32_t dy_voff = (uint32_t)(lrow * (int)dy_row_bytes + src_chunk * 16);
+  const uint32_t a_voff = (uint32_t)(lrow * (int)a_row_bytes + src_chunk * 16);
+  const char* dy_base = p.dY + (long long)(p.dy_coff + n0) * 2;
+  const char* a_base = p.A + (long long)(p.a_coff + k0) * 2;
 
   // transposed-read lane geometry: group g = lane/16 reads pixels 4g+q (first read) and 16+4g+q
   // (second read); q = (lane/4)&3 is the block row this lane addresses, pc = lane&3 the 4-channel column.
@@ -92,15 +96,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs p) {
     __syncthreads();  // previous stage fully consumed
     // ---- stage dY[128 rows] and the A bands -------------------------------------------------
     for (int gi = wave; gi < C::NGROUPS; gi += 4) {
-      const char* src;
+      const char* base;
+      uint32_t voff;
       if (gi < 16) {
-        src = dy_lane + (mb + gi * 8) * dy_row_bytes;
+        base = dy_base + (mb + gi * 8) * dy_row_bytes;
+        voff = dy_voff;
       } else {
         const int band = (gi - 16) / C::BAND_GROUPS, bg = (gi - 16) % C::BAND_GROUPS;
         const long long r0 = (T == 9) ? (mb + (long long)(band - 1) * p.Wp - 1) : mb;
-        src = a_lane + (r0 + bg * 8) * a_row_bytes;
+        base = a_base + (r0 + bg * 8) * a_row_bytes;
+        voff = a_voff;
       }
-      __builtin_amdgcn_global_load_lds((const UH_GLOBAL void*)src, (UH_LDS void*)(smem + gi * 1024), 16, 0, 0);
+      const uint32_t lds_addr = (uint32_t)(uintptr_t)(UH_LDS char*)(smem + gi * 1024);
+      asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory");
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -199,11 +207,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_col_kernel(WgradArgs p) {
   long long me = ms + p.rows_per_split;
   if (me > total) me = total;
 
+  // A DMA's source is a wave-uniform base (scalar registers, scalar arithmetic) plus this lane's fixed 32-bit offset
+  // inside a group of eight rows: two VGPRs for addressing in all, and no vector instructions per DMA.
   const int lrow = lane >> 3;
   const int src_chunk = (lane & 7) ^ (((lane >> 4) & 3) << 1);
-  const long long dy_row_bytes = (long long)p.dy_cstride * 2, a_row_bytes = (long long)p.a_cstride * 2;
-  const char* dy_lane = p.dY + (long long)lrow * dy_row_bytes + (long long)(p.dy_coff + n0) * 2 + src_chunk * 16;
-  const char* a_lane = p.A + (long long)lrow * a_row_bytes + (long long)(p.a_coff + k0) * 2 + src_chunk * 16;
+  const int dy_rb = p.dy_cstride * 2, a_rb = p.a_cstride * 2;
+  const uint32_t dy_voff = (uint32_t)(lrow * dy_rb + src_chunk * 16);
+  const uint32_t a_voff = (uint32_t)(lrow * a_rb + src_chunk * 16);
+  const char* dy_base = p.dY + (long long)(p.dy_coff + n0) * 2;
+  const char* a_base = p.A + (long long)(p.a_coff + k0) * 2;
   const int g = lane >> 4, q = (lane >> 2) & 3, pc = lane & 3;
   const int px = 4 * g + q;
 
@@ -213,51 +225,45 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_col_kernel(WgradArgs p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // Written as assembly on purpose: behind the builtin the compiler puts a full s_waitcnt vmcnt(0) in front of
+  // every transposing LDS read that follows (it cannot tell which slot the DMA fills), which would undo the
+  // prefetch; the waits for these loads are the explicit ones at the end of each stage.
+  auto dma = [&](const char* base, uint32_t voff, int dst) {
+    const uint32_t lds_addr = (uint32_t)(uintptr_t)(UH_LDS char*)(smem + dst);
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory");
+  };
   // dY of the stage at pixel mb into buffer db; bands first .. 2 of it into their slots (rot + d) & 3
   auto issue = [&](long long mb, int db, int rot, int first) {
     const int ngroups = 8 + (3 - first) * C::BAND_GROUPS;
     for (int gi = wave; gi < ngroups; gi += 4) {
-      const char* src;
-      int dst;
       if (gi < 8) {
-        src = dy_lane + (mb + gi * 8) * dy_row_bytes;
-        dst = db * C::DY_BYTES + gi * 1024;
+        dma(dy_base + (mb + gi * 8) * dy_rb, dy_voff, db * C::DY_BYTES + gi * 1024);
       } else {
         const int bi = (gi - 8) / C::BAND_GROUPS, bg = (gi - 8) % C::BAND_GROUPS;
         const int d = first + bi;
-        src = a_lane + (mb + (long long)(d - 1) * p.Wp - 1 + bg * 8) * a_row_bytes;
-        dst = C::BAND_OFF + ((rot + d) & 3) * C::BAND_BYTES + bg * 1024;
+        dma(a_base + (mb + (long long)(d - 1) * p.Wp - 1 + bg * 8) * a_rb, a_voff,
+            C::BAND_OFF + ((rot + d) & 3) * C::BAND_BYTES + bg * 1024);
       }
-      // Written as assembly on purpose: behind the builtin the compiler puts a full s_waitcnt vmcnt(0) in front of
-      // every transposing LDS read that follows (it cannot tell which slot the DMA fills), which would undo the
-      // prefetch; the waits for these loads are the explicit ones at the end of each stage.
-      const uint32_t lds_addr = (uint32_t)(uintptr_t)(UH_LDS char*)(smem + dst);
-      asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_addr), "v"(src) : "memory");
     }
   };
   // The common case, the next image row of the same strip (dY + the one new band, into slot (rot + 2) & 3 counted from
-  // the rotation the ring will then have), with nothing but pointer additions per stage: a wave's two dY groups
+  // the rotation the ring will then have), with nothing but scalar additions per stage: a wave's two dY groups
   // (wave, wave + 4) and two or three band groups (wave, wave + 4, and 8 for wave 0) sit at fixed offsets from the
-  // stage's first pixel, and the pointers to that pixel advance by one image row.  (Measured with cycle stamps: the
+  // stage's first pixel, and the bases of that pixel advance by one image row.  (Measured with cycle stamps: the
   // general form above, with its 64-bit products and the division that finds a stage's strip, took as long per
   // stage as the stage's 72 MFMAs.)
-  const int dy_rb = p.dy_cstride * 2, a_rb = p.a_cstride * 2;
   const int dy_g0 = wave * 8 * dy_rb, dy_g1 = (wave + 4) * 8 * dy_rb;
   const int a_g0 = wave * 8 * a_rb, a_g1 = (wave + 4) * 8 * a_rb, a_g2 = 8 * 8 * a_rb;
   const long long dy_step = (long long)p.Wp * dy_rb, a_step = (long long)p.Wp * a_rb;
-  const char* a_new = a_lane + (long long)(p.Wp - 1) * a_rb;       // band 2 of a stage starts Wp - 1 pixels behind it
-  auto dma = [&](const char* src, int dst) {
-    const uint32_t lds_addr = (uint32_t)(uintptr_t)(UH_LDS char*)(smem + dst);
-    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_addr), "v"(src) : "memory");
-  };
+  const char* a_new = a_base + (long long)(p.Wp - 1) * a_rb;       // band 2 of a stage starts Wp - 1 pixels behind it
   auto issue_next_row = [&](const char* dyp, const char* ap, int db_n, int rot_n) {
     const int dyb = db_n * C::DY_BYTES + wave * 1024;
     const int bnd = C::BAND_OFF + ((rot_n + 2) & 3) * C::BAND_BYTES + wave * 1024;
-    dma(dyp + dy_g0, dyb);
-    dma(dyp + dy_g1, dyb + 4096);
-    dma(ap + a_g0, bnd);
-    dma(ap + a_g1, bnd + 4096);
-    if (wave == 0) dma(ap + a_g2, bnd + 8192);
+    dma(dyp + dy_g0, dy_voff, dyb);
+    dma(dyp + dy_g1, dy_voff, dyb + 4096);
+    dma(ap + a_g0, a_voff, bnd);
+    dma(ap + a_g1, a_voff, bnd + 4096);
+    if (wave == 0) dma(ap + a_g2, a_voff, bnd + 8192);
   };
 
   if (ms < me) {
@@ -265,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_col_kernel(WgradArgs p) {
     int strip = (int)(ms / p.total_rows);
     int row = (int)(ms - (long long)strip * p.total_rows);
     long long mb = (long long)row * p.Wp + strip * 64;
-    const char* dyp = dy_lane + mb * dy_rb;                         // this stage's first pixel, this lane's piece
+    const char* dyp = dy_base + mb * dy_rb;                         // this stage's first pixel (wave-uniform)
     const char* ap = a_new + mb * a_rb;
     issue(mb, 0, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -325,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_col_kernel(WgradArgs p) {
         row = 0;
         ++strip;
         mb = (long long)strip * 64;
-        dyp = dy_lane + mb * dy_rb;
+        dyp = dy_base + mb * dy_rb;
         ap = a_new + mb * a_rb;
         issue(mb, db ^ 1, 0, 0);
       }
