@@ -248,9 +248,12 @@ def test_conv_wgrad(B, H, W, Cin, Cout):
     close(dw, want, 2e-3, "wgrad (fp32 accumulate of bf16 products)")
 
 
-def test_conv_wgrad_1x1_and_transposed():
-    """T=1 weight gradient as used for the transposed conv: space-to-depth then GEMM."""
-    B, h, w, Cin, Cout = 2, 4, 6, 128, 64
+@pytest.mark.parametrize("B,h,w,Cin,Cout", [(2, 4, 6, 128, 64), (2, 4, 6, 64, 64), (3, 10, 9, 256, 128),
+                                            (1, 16, 16, 128, 32), (8, 100, 100, 256, 128)])
+def test_conv_wgrad_1x1_and_transposed(B, h, w, Cin, Cout):
+    """T=1 weight gradient as used for the transposed conv: space-to-depth then GEMM.  (The last case is large enough,
+    21 GFLOP with N = 4 Cout and K = Cin multiples of 128, for the 128 x 128-block kernel; the others take 64 x 64
+    blocks.)"""
     g = torch.Generator().manual_seed(37)
     x = bf(torch.randn(B, Cin, h, w, generator=g))
     dy = bf(torch.randn(B, Cout, 2 * h, 2 * w, generator=g))

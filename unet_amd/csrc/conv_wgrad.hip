@@ -166,6 +166,123 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs p) {
       }
 }
 
+// ---- T = 1, N and K multiples of 128: a 128 x 128 block per workgroup ---------------------------------------------------
+// With one tap a 64 x 64 block stages 32 KB per 128 pixels for 16 MFMAs per wave: cycle stamps put the issue of its eight
+// DMA instructions per wave at 1500-1700 cycles a stage against 650 for the arithmetic, and every staged byte is fetched
+// from L2 once per block that needs it.  A 128 x 128 block stages 64 KB for four times the MFMAs: half the DMA
+// instructions and half the L2 reads per MFMA.  LDS holds four images of 128 pixels x 64 channels (dY low / high half,
+// A low / high half), each laid out and read like the 64-channel images of conv_wgrad_kernel; wave w owns k columns
+// 32 w .. 32 w + 31 of the block and all 128 n rows (acc: 8 x 2 tiles).
+struct WWideCfg {
+  static constexpr int IMG_BYTES = 128 * 128;      // one image: 128 pixels x 64 channels
+  static constexpr int LDS_BYTES = 4 * IMG_BYTES;
+  static constexpr int NGROUPS = 64;               // 16 eight-row groups per image
+};
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad1_wide_kernel(WgradArgs p) {
+  using C = WWideCfg;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int n0, k0, split;                 // as in conv_wgrad_kernel, with 128 x 128 blocks
+  if (p.remap) {
+    const int tn = p.N / 128, tiles = tn * (p.K / 128);
+    const int q = blockIdx.x >> 3;
+    split = (blockIdx.x & 7) + 8 * (q / tiles);
+    if (split >= p.S) return;
+    const int t = q % tiles;
+    n0 = (t % tn) * 128;
+    k0 = (t / tn) * 128;
+  } else {
+    n0 = blockIdx.x * 128;
+    k0 = blockIdx.y * 128;
+    split = blockIdx.z;
+  }
+  const long long ms = (long long)split * p.rows_per_split;
+  long long me = ms + p.rows_per_split;
+  if (me > ((p.Mp + 127) / 128) * 128) me = ((p.Mp + 127) / 128) * 128;
+
+  const int lrow = lane >> 3;
+  const int src_chunk = (lane & 7) ^ (((lane >> 4) & 3) << 1);
+  const long long dy_row_bytes = (long long)p.dy_cstride * 2, a_row_bytes = (long long)p.a_cstride * 2;
+  const uint32_t dy_voff = (uint32_t)(lrow * (int)dy_row_bytes + src_chunk * 16);
+  const uint32_t a_voff = (uint32_t)(lrow * (int)a_row_bytes + src_chunk * 16);
+  const char* dy_base = p.dY + (long long)(p.dy_coff + n0) * 2;
+  const char* a_base = p.A + (long long)(p.a_coff + k0) * 2;
+  const int g = lane >> 4, q = (lane >> 2) & 3, pc = lane & 3;
+  const int px = 4 * g + q;
+
+  f32x4 acc[8][2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) acc[i][kk] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (long long mb = ms; mb < me; mb += 128) {
+    __syncthreads();  // previous stage fully consumed
+    for (int gi = wave; gi < C::NGROUPS; gi += 4) {
+      const int img = gi >> 4, gr = gi & 15;       // image 0, 1: dY channels 0-63, 64-127; 2, 3: A likewise
+      const char* base = (img < 2 ? dy_base + (mb + gr * 8) * dy_row_bytes : a_base + (mb + gr * 8) * a_row_bytes) +
+                         (img & 1) * 128;
+      const uint32_t voff = img < 2 ? dy_voff : a_voff;
+      const uint32_t lds_addr = (uint32_t)(uintptr_t)(UH_LDS char*)(smem + gi * 1024);
+      asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 af[8];                                // dY^T: 8 n-subtiles of 16 channels
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        bf16x4 lo, hi;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int r = ks * 32 + px + 16 * h;
+          const int chunk = (2 * (i & 3) + (pc >> 1)) ^ (((r >> 1) & 3) << 1);
+          const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+              (UH_LDS bf16x4*)(smem + (i >> 2) * C::IMG_BYTES + r * 128 + chunk * 16 + (pc & 1) * 8));
+          if (h == 0) lo = v; else hi = v;
+        }
+        af[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int k16 = wave * 2 + kk;             // 16-column subtile of the block's 128 k columns
+        bf16x4 lo, hi;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int r = ks * 32 + px + 16 * h;
+          const int chunk = (2 * (k16 & 3) + (pc >> 1)) ^ (((r >> 1) & 3) << 1);
+          const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+              (UH_LDS bf16x4*)(smem + (2 + (k16 >> 2)) * C::IMG_BYTES + r * 128 + chunk * 16 + (pc & 1) * 8));
+          if (h == 0) lo = v; else hi = v;
+        }
+        const bf16x8 bfr = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          acc[i][kk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr, acc[i][kk], 0, 0, 0);
+      }
+    }
+  }
+
+  // partial[split][n][k]
+  const int l15 = lane & 15;
+  float* base = p.partial + (long long)split * p.N * p.K;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = n0 + i * 16 + g * 4 + e;
+        const int k = k0 + (wave * 2 + kk) * 16 + l15;
+        base[(long long)n * p.K + k] = acc[i][kk][e];
+      }
+}
+
 // ---- T = 9, W a multiple of 64: column walk with a rotating band ring and one stage of prefetch ------------------------
 // A split walks DOWN a 64-pixel-wide column strip, one image row per stage (the pad column, whose dY is zero, is
 // never visited).  The A bands of filter rows 0, 1, 2 of a stage are then the bands of rows 1, 2 of the previous stage
@@ -355,10 +472,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_col_kernel(WgradArgs p) {
       }
 }
 
+// T = 1 launches whose N and K are multiples of 128 take 128 x 128 blocks if they are large (UNET_AMD_WGRAD1_WIDE=0:
+// never).  ~512 workgroups write 33 MB of partial blocks instead of 8, which the reduction then reads: measured, the
+// U-Net's four transposed convolutions (35-39 GFLOP each) go from 395 to 261 us and its step from 13.66 to 13.55 ms,
+// while LUNeXt's 1x1 and 2x2 layers (<= 10 GFLOP) lose more in the reduction than they gain (step 5.61 -> 5.69 ms).
+static bool wgrad1_wide(long long Mp, int N, int K, int T) {
+  static const bool on = [] { const char* e = getenv("UNET_AMD_WGRAD1_WIDE"); return !e || atoi(e) != 0; }();
+  return on && T == 1 && N % 128 == 0 && K % 128 == 0 && 2.0 * (double)Mp * N * K >= 2e10;
+}
+
 static int wgrad_splits(long long Mp, int N, int K, int T) {
   const long long stages = (Mp + 127) / 128;
-  const long long tiles = (long long)(N / 64) * (K / 64);
-  (void)T;
+  const int edge = wgrad1_wide(Mp, N, K, T) ? 128 : 64;
+  const long long tiles = (long long)(N / edge) * (K / edge);
   static const int target = [] { const char* e = getenv("UNET_AMD_WGRAD_WGS"); return e ? atoi(e) : 512; }();
   long long want = (target + tiles - 1) / tiles;     // aim at ~512 workgroups (two per CU): every split costs a slab
   if (want > stages) want = stages;
@@ -411,10 +537,14 @@ extern "C" int uh_conv_wgrad(int B, int H, int W, const void* dy, int dy_cstride
   p.Wp = W + 1;
   p.S = S;
   p.remap = (S >= 8) ? 1 : 0;
-  dim3 grid(N / 64, K / 64, S);
-  if (p.remap) grid = dim3((unsigned)(8 * ((S + 7) / 8) * (N / 64) * (K / 64)), 1, 1);
+  const int edge = wgrad1_wide(p.Mp, N, K, T) ? 128 : 64;
+  dim3 grid(N / edge, K / edge, S);
+  if (p.remap) grid = dim3((unsigned)(8 * ((S + 7) / 8) * (N / edge) * (K / edge)), 1, 1);
   hipStream_t st = (hipStream_t)s;
-  if (col64) {
+  if (edge == 128) {
+    uh_set_max_lds((const void*)conv_wgrad1_wide_kernel, WWideCfg::LDS_BYTES);
+    hipLaunchKernelGGL(conv_wgrad1_wide_kernel, grid, dim3(256), WWideCfg::LDS_BYTES, st, p);
+  } else if (col64) {
     hipLaunchKernelGGL(conv_wgrad_col_kernel, grid, dim3(256), WColCfg::LDS_BYTES, st, p);
   } else if (T == 9) {
     uh_set_max_lds((const void*)conv_wgrad_kernel<9>, WCfg<9>::LDS_BYTES);
