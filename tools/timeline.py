@@ -11,7 +11,7 @@ step = rows[a:b]
 t0 = int(step[0]["Start_Timestamp"])
 def cls(n):
     if "conv_band_kernel" in n or "conv_stream" in n or "conv_gemm_kernel" in n: return "M"
-    if "conv_wgrad_kernel" in n or "conv_wgrad_col_kernel" in n: return "W"
+    if "conv_wgrad_kernel" in n or "conv_wgrad_col_kernel" in n or "conv_wgrad1_wide_kernel" in n: return "W"
     return "h"
 def union(iv):
     iv = sorted(iv); tot = 0; cs, ce = None, None
