@@ -203,7 +203,9 @@ def test_conv_dgrad(B, H, W, Cin, Cout):
     pads_are_zero(out)
 
 
-@pytest.mark.parametrize("B,h,w,Cin,Cout", [(2, 4, 4, 128, 64), (1, 2, 6, 64, 64), (2, 8, 8, 256, 128)])
+@pytest.mark.parametrize("B,h,w,Cin,Cout", [(2, 4, 4, 128, 64), (1, 2, 6, 64, 64), (2, 8, 8, 256, 128),
+                                            # at least 512 tiles of 256 x 256: the sixteen-wave kernel
+                                            (8, 128, 128, 128, 64), (6, 150, 120, 64, 128)])
 def test_conv_transpose_fwd(B, h, w, Cin, Cout):
     g = torch.Generator().manual_seed(23)
     x = bf(torch.randn(B, Cin, h, w, generator=g))
@@ -249,11 +251,11 @@ def test_conv_wgrad(B, H, W, Cin, Cout):
 
 
 @pytest.mark.parametrize("B,h,w,Cin,Cout", [(2, 4, 6, 128, 64), (2, 4, 6, 64, 64), (3, 10, 9, 256, 128),
-                                            (1, 16, 16, 128, 32), (8, 100, 100, 256, 128)])
+                                            (1, 16, 16, 128, 32), (8, 100, 100, 256, 128), (8, 130, 130, 256, 64)])
 def test_conv_wgrad_1x1_and_transposed(B, h, w, Cin, Cout):
     """T=1 weight gradient as used for the transposed conv: space-to-depth then GEMM.  (The last case is large enough,
     21 GFLOP with N = 4 Cout and K = Cin multiples of 128, for the 128 x 128-block kernel; the others take 64 x 64
-    blocks.)"""
+    blocks.  The last case's input gradient has 537 tiles of 256 x 256: the sixteen-wave GEMM kernel.)"""
     g = torch.Generator().manual_seed(37)
     x = bf(torch.randn(B, Cin, h, w, generator=g))
     dy = bf(torch.randn(B, Cout, 2 * h, 2 * w, generator=g))

@@ -544,15 +544,17 @@ __global__ __launch_bounds__(512) void conv_band_fixup_kernel(GemmArgs p, BandSc
 // These GEMMs are short (K = 128 ... 2048) and the largest are HBM-bound (transposed convolution at full resolution:
 // 408 MB moved for 35 GFLOP), so what matters is that the ring runs on across tile boundaries and that stores of one
 // tile overlap the loads of the next.
-template <int BM, int BN>
+// NW waves per workgroup: eight 64x64 waves (tiles 256x128 / 512x64), or sixteen for a 256x256 tile, which stages a
+// third fewer bytes and DMA instructions per MFMA (32 KB for 256 MFMAs instead of 24 KB for 128).
+template <int BM, int BN, int NW = 8>
 struct StreamCfg {
   static constexpr int WN = BN / 64;
-  static constexpr int WM = 8 / WN;
-  static_assert(BM == WM * 64, "each of the eight waves owns 64 rows");
+  static constexpr int WM = NW / WN;
+  static_assert(BM == WM * 64, "each wave owns 64 rows");
   static constexpr int AG = BM / 16;              // 1 KiB groups (16 rows x 64 B) of the A slice
   static constexpr int BG = BN / 16;
   static constexpr int SG = AG + BG;
-  static constexpr int NQ = (SG + 7) / 8;         // staging slots per wave
+  static constexpr int NQ = (SG + NW - 1) / NW;   // staging slots per wave
   static constexpr int STAGE = SG * 1024;
   // stage s + DIST is issued while stage s is consumed, into the buffer that held stage s - 2 (ring of DIST + 2).
   // DIST = 3 (five stages, 126 KB at 256 x 128) was measured on the four transposed convolutions and their input
@@ -561,9 +563,9 @@ struct StreamCfg {
   static constexpr int DIST = 2;
   static constexpr int NSTAGE = DIST + 2;
   static constexpr int FLAG_OFF = NSTAGE * STAGE;
-  static constexpr int RED_OFF = FLAG_OFF + 8 * 256;
-  static constexpr int COEF_OFF = RED_OFF + WM * 2 * BN * 4;  // 8 waves x float[4][64], as in BandCfg
-  static constexpr int LDS_BYTES = COEF_OFF + 8 * 1024;
+  static constexpr int RED_OFF = FLAG_OFF + NW * 256;
+  static constexpr int COEF_OFF = RED_OFF + WM * 2 * BN * 4;  // NW waves x float[4][64], as in BandCfg
+  static constexpr int LDS_BYTES = COEF_OFF + NW * 1024;
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
@@ -638,9 +640,11 @@ __device__ __forceinline__ void stream_epilogue_convt(const GemmArgs& p, const f
   }
 }
 
-template <int BM, int BN, int MODE>
-__global__ __launch_bounds__(512) void conv_stream_kernel(GemmArgs p, BandSched sc) {
-  using C = StreamCfg<BM, BN>;
+template <int BM, int BN, int MODE, int NW = 8>
+__global__ __launch_bounds__(NW * 64) void conv_stream_kernel(GemmArgs p, BandSched sc) {
+  using C = StreamCfg<BM, BN, NW>;
+  static_assert(NW == 8 || (MODE != UH_EPI_RAW_STATS && MODE != UH_EPI_MASKED_BNBWD),
+                "the statistics epilogues reduce over eight waves");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int niter = sc.niter, ntn = sc.ntn;        // niter = K/32
   // whole units per workgroup; each XCD (workgroups b, b+8, ...) owns one contiguous range of units
@@ -667,7 +671,7 @@ __global__ __launch_bounds__(512) void conv_stream_kernel(GemmArgs p, BandSched 
   bool slot_is_a[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
-    const int gi = wave + 8 * q;
+    const int gi = wave + NW * q;
     slot_is_a[q] = gi < C::AG;
     const int nb = gi - C::AG;
     const int chan = (nb >> 2) * 64 + srow * 4 + (nb & 3);
@@ -675,14 +679,14 @@ __global__ __launch_bounds__(512) void conv_stream_kernel(GemmArgs p, BandSched 
     const char* pb = p.Wt + (long long)chan * b_row_bytes + src_chunk * 16;
     gp[q] = slot_is_a[q] ? pa : pb;
   }
-  const bool has_last = wave + 8 * (NQ - 1) < C::SG;
+  const bool has_last = wave + NW * (NQ - 1) < C::SG;
   auto issue_stage = [&](int buf, long long offA, long long offB) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       if (q == NQ - 1 && !has_last) break;
       const long long off = slot_is_a[q] ? offA : offB;
       __builtin_amdgcn_global_load_lds((const UH_GLOBAL void*)(gp[q] + off),
-                                       (UH_LDS void*)(smem + buf * C::STAGE + (wave + 8 * q) * 1024), 16, 0, 0);
+                                       (UH_LDS void*)(smem + buf * C::STAGE + (wave + NW * q) * 1024), 16, 0, 0);
     }
   };
   const long long mask_last_dword = (p.Mp - 1) >> 2;
@@ -764,7 +768,7 @@ __global__ __launch_bounds__(512) void conv_stream_kernel(GemmArgs p, BandSched 
   }
   wait_stages(issued - 1);                      // stage 0 has landed
   __builtin_amdgcn_s_barrier();
-  if (wave >= 4) __builtin_amdgcn_s_barrier();  // the stagger
+  if (wave >= NW / 2) __builtin_amdgcn_s_barrier();  // the stagger
 
   int buf = 0, s = 0;
   int pend_mt = -1, pend_nt = 0;
@@ -789,9 +793,11 @@ __global__ __launch_bounds__(512) void conv_stream_kernel(GemmArgs p, BandSched 
         issue_flags(mt);
         issue_coef(nt);
       }
-      if ((MODE == UH_EPI_RAW_STATS || MODE == UH_EPI_MASKED_BNBWD) && c == 1 && pend_mt >= 0) {
-        band_flush_stats<BM, BN>(p, red, pend_mt, pend_nt, tid);
-        pend_mt = -1;
+      if constexpr (MODE == UH_EPI_RAW_STATS || MODE == UH_EPI_MASKED_BNBWD) {
+        if (c == 1 && pend_mt >= 0) {
+          band_flush_stats<BM, BN>(p, red, pend_mt, pend_nt, tid);
+          pend_mt = -1;
+        }
       }
       if (s + DIST < total) {
         advance();
@@ -836,10 +842,12 @@ __global__ __launch_bounds__(512) void conv_stream_kernel(GemmArgs p, BandSched 
     }
     u += u_step;
   }
-  if (wave < 4) __builtin_amdgcn_s_barrier();   // match the second half's extra barrier
-  if ((MODE == UH_EPI_RAW_STATS || MODE == UH_EPI_MASKED_BNBWD) && pend_mt >= 0) {
-    __syncthreads();
-    band_flush_stats<BM, BN>(p, red, pend_mt, pend_nt, tid);
+  if (wave < NW / 2) __builtin_amdgcn_s_barrier();   // match the second half's extra barrier
+  if constexpr (MODE == UH_EPI_RAW_STATS || MODE == UH_EPI_MASKED_BNBWD) {
+    if (pend_mt >= 0) {
+      __syncthreads();
+      band_flush_stats<BM, BN>(p, red, pend_mt, pend_nt, tid);
+    }
   }
 }
 
@@ -915,11 +923,34 @@ static void launch_band(const GemmArgs& p, void* ws, size_t ws_bytes, hipStream_
   else launch_band_mode<BM, BN, UH_EPI_MASKED>(p, sc, st);
 }
 
-template <int BM, int BN, int MODE>
+template <int BM, int BN, int MODE, int NW = 8>
 static void launch_stream_mode(const GemmArgs& p, const BandSched& sc, hipStream_t st) {
-  using C = StreamCfg<BM, BN>;
-  uh_set_max_lds((const void*)conv_stream_kernel<BM, BN, MODE>, C::LDS_BYTES);
-  hipLaunchKernelGGL((conv_stream_kernel<BM, BN, MODE>), dim3(sc.G), dim3(512), C::LDS_BYTES, st, p, sc);
+  using C = StreamCfg<BM, BN, NW>;
+  uh_set_max_lds((const void*)conv_stream_kernel<BM, BN, MODE, NW>, C::LDS_BYTES);
+  hipLaunchKernelGGL((conv_stream_kernel<BM, BN, MODE, NW>), dim3(sc.G), dim3(NW * 64), C::LDS_BYTES, st, p, sc);
+}
+
+// 256 x 256 tiles on sixteen waves: transposed convolutions and masked GEMMs whose N is a multiple of 256 and that have
+// at least two rounds of such tiles (UNET_AMD_STREAM_WIDE=0: never)
+static bool stream_wide(const GemmArgs& p) {
+  static const bool on = [] { const char* e = getenv("UNET_AMD_STREAM_WIDE"); return !e || atoi(e) != 0; }();
+  if (!on || p.N % 256 != 0 || (p.mode != UH_EPI_MASKED && p.mode != UH_EPI_CONVT)) return false;
+  return ((p.Mp + 255) / 256) * (p.N / 256) >= 512;
+}
+
+static void launch_stream_wide(const GemmArgs& p, hipStream_t st) {
+  BandSched sc;
+  sc.ntm = (int)((p.Mp + 255) / 256);
+  sc.ntn = p.N / 256;
+  sc.niter = p.K / 32;
+  const long long units = (long long)sc.ntm * sc.ntn;
+  sc.G = band_workgroups(units, sc.niter);
+  sc.ws = nullptr;
+  sc.upx = (int)((units + 7) / 8);
+  sc.aligned = 1;
+  sc.nmajor = 0;
+  if (p.mode == UH_EPI_MASKED) launch_stream_mode<256, 256, UH_EPI_MASKED, 16>(p, sc, st);
+  else launch_stream_mode<256, 256, UH_EPI_CONVT, 16>(p, sc, st);
 }
 
 template <int BM, int BN>
@@ -1026,6 +1057,8 @@ extern "C" int uh_conv_gemm_ws(int B, int H, int W, const void* a, int a_cstride
       launch_band<512, 64>(p, workspace, workspace_bytes, st);
     else
       launch_band<256, 128>(p, workspace, workspace_bytes, st);
+  } else if (stream_wide(p)) {
+    launch_stream_wide(p, st);
   } else if (use_wide_m(N)) {
     launch_stream<512, 64>(p, st);
   } else {
