@@ -233,7 +233,9 @@ def test_conv_transpose_fwd(B, h, w, Cin, Cout):
                                             # widths that are multiples of 64 walk down column strips
                                             (1, 6, 128, 64, 64), (2, 3, 256, 128, 64), (3, 5, 128, 64, 128),
                                             (2, 40, 256, 64, 64), (2, 10, 64, 64, 64), (1, 1, 64, 64, 64),
-                                            (5, 64, 64, 128, 128)])
+                                            (5, 64, 64, 128, 128),
+                                            # wider than 138 and no multiple of 64: three separate bands per stage
+                                            (1, 4, 150, 64, 64), (2, 3, 139, 64, 128), (1, 5, 138, 64, 64)])
 def test_conv_wgrad(B, H, W, Cin, Cout):
     g = torch.Generator().manual_seed(31)
     x = bf(torch.randn(B, Cin, H, W, generator=g))

@@ -40,9 +40,14 @@ struct WCfg {
   static constexpr int NGROUPS = 16 + BANDS * BAND_GROUPS;
 };
 
-template <int T>
+// MERGED (T = 9, narrow images): the three A bands of a stage are the same rows one image row apart, so where
+// 130 + 2 Wp rows fit the three band slots ONE image of that many rows is staged and filter row ky reads it ky * Wp rows
+// further down: at W = 32 a stage is 41 KB instead of 67 (cycle stamps had the 17 DMA instructions per wave of a stage
+// take as long to issue as its 144 MFMAs).
+template <int T, bool MERGED>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs p) {
   using C = WCfg<T>;
+  static_assert(!MERGED || T == 9, "one tap has one band");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -95,12 +100,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs p) {
   for (long long mb = ms; mb < me; mb += 128) {
     __syncthreads();  // previous stage fully consumed
     // ---- stage dY[128 rows] and the A bands -------------------------------------------------
-    for (int gi = wave; gi < C::NGROUPS; gi += 4) {
+    const int ngroups = MERGED ? 16 + (130 + 2 * p.Wp + 7) / 8 : C::NGROUPS;
+    for (int gi = wave; gi < ngroups; gi += 4) {
       const char* base;
       uint32_t voff;
       if (gi < 16) {
         base = dy_base + (mb + gi * 8) * dy_row_bytes;
         voff = dy_voff;
+      } else if (MERGED) {
+        base = a_base + (mb - p.Wp - 1 + (gi - 16) * 8) * a_row_bytes;
+        voff = a_voff;
       } else {
         const int band = (gi - 16) / C::BAND_GROUPS, bg = (gi - 16) % C::BAND_GROUPS;
         const long long r0 = (T == 9) ? (mb + (long long)(band - 1) * p.Wp - 1) : mb;
@@ -137,10 +146,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs p) {
         bf16x4 lo, hi;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const int r = ks * 32 + px + 16 * h + kx;   // row inside the band
+          // row inside the band (MERGED: inside the one image, filter row `band` sits band * Wp rows further down)
+          const int r = ks * 32 + px + 16 * h + kx + (MERGED ? band * p.Wp : 0);
           const int chunk = (2 * wave + (pc >> 1)) ^ (((r >> 1) & 3) << 1);
           const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-              (UH_LDS bf16x4*)(smem + C::DY_BYTES + band * C::BAND_BYTES + r * 128 + chunk * 16 + (pc & 1) * 8));
+              (UH_LDS bf16x4*)(smem + C::DY_BYTES + (MERGED ? 0 : band * C::BAND_BYTES) + r * 128 + chunk * 16 +
+                               (pc & 1) * 8));
           if (h == 0) lo = v; else hi = v;
         }
         const bf16x8 bfr = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -547,10 +558,16 @@ extern "C" int uh_conv_wgrad(int B, int H, int W, const void* dy, int dy_cstride
   } else if (col64) {
     hipLaunchKernelGGL(conv_wgrad_col_kernel, grid, dim3(256), WColCfg::LDS_BYTES, st, p);
   } else if (T == 9) {
-    uh_set_max_lds((const void*)conv_wgrad_kernel<9>, WCfg<9>::LDS_BYTES);
-    hipLaunchKernelGGL((conv_wgrad_kernel<9>), grid, dim3(256), WCfg<9>::LDS_BYTES, st, p);
+    static const bool merge_on = [] { const char* e = getenv("UNET_AMD_WGRAD_MERGE"); return !e || atoi(e) != 0; }();
+    if (merge_on && 130 + 2 * p.Wp <= 3 * WCfg<9>::BAND_GROUPS * 8) {
+      uh_set_max_lds((const void*)conv_wgrad_kernel<9, true>, WCfg<9>::LDS_BYTES);
+      hipLaunchKernelGGL((conv_wgrad_kernel<9, true>), grid, dim3(256), WCfg<9>::LDS_BYTES, st, p);
+    } else {
+      uh_set_max_lds((const void*)conv_wgrad_kernel<9, false>, WCfg<9>::LDS_BYTES);
+      hipLaunchKernelGGL((conv_wgrad_kernel<9, false>), grid, dim3(256), WCfg<9>::LDS_BYTES, st, p);
+    }
   } else {
-    hipLaunchKernelGGL((conv_wgrad_kernel<1>), grid, dim3(256), WCfg<1>::LDS_BYTES, st, p);
+    hipLaunchKernelGGL((conv_wgrad_kernel<1, false>), grid, dim3(256), WCfg<1>::LDS_BYTES, st, p);
   }
   return uh_check_launch("conv_wgrad");
 }
