@@ -27,6 +27,34 @@ IMG = 256
 FLOP_PER_IMG_FWD_BWD = 288.8e9   # 3 x 96.33 GFLOP forward (2*MAC, all convs) - conv1_1 input gradient, at 256x256
 
 
+def synth_batch(b, c, h, w, seed_img=1234, seed_mask=4321):
+    """Synthetic batch of the loaders' value ranges (data_helpers/utils.py:58-62,106): images uniform in [0, 1),
+    masks in {0, 1}; fp32 NCHW, on the host."""
+    import torch
+    gi = torch.Generator().manual_seed(seed_img)
+    gm = torch.Generator().manual_seed(seed_mask)
+    x = torch.rand(b, c, h, w, generator=gi)
+    m = (torch.rand(b, 1, h, w, generator=gm) > 0.5).float()
+    return x, m
+
+
+def launch_ranks(n, argv, script=None):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks as a child job (one process per GPU) and relay
+    rank 0's JSON line and the job's exit code.  Called before this process has imported torch or touched the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script or os.path.abspath(__file__)] + argv
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    return proc.returncode if lines or proc.returncode else 1
+
+
 def cpu_baseline(threads):
     """fp32 CPU oracle, fwd + BCE + bwd + Adam, on 4 images of the same 3x256x256 workload."""
     import torch
@@ -61,14 +89,13 @@ def lunext_result(args, with_cpu_baseline):
     HBM-bound; `roofline` prices the clDice loss (forward + backward) against the HBM peak."""
     import torch
     import unet_amd
-    from oracle import ref_cpu
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     torch.manual_seed(0)
     model = unet_amd.LUNeXt(3, 1).to(dev).train()
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
     crit = unet_amd.soft_dice_cldice()
-    x, m = ref_cpu.synth_batch(args.batch, 3, args.size, args.size)
+    x, m = synth_batch(args.batch, 3, args.size, args.size)
     x, m = x.to(dev), m.to(dev)
 
     def step():
@@ -112,6 +139,7 @@ def lunext_result(args, with_cpu_baseline):
                         "frac": round(achieved / PEAK_HBM, 4), "traffic": None,
                         "ms_per_call": round(t_loss * 1e3, 3), "bytes_per_pixel": CLDICE_BYTES_PER_PIXEL}}
     if with_cpu_baseline:
+        from oracle import ref_cpu
         threads = int(os.environ.get("OMP_NUM_THREADS", min(16, os.cpu_count() or 1)))
         torch.set_num_threads(threads)
         torch.manual_seed(0)
@@ -151,6 +179,8 @@ def main():
         print(json.dumps(lunext_result(args, not args.no_cpu_baseline)), flush=True)
         return
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -171,7 +201,6 @@ def main():
     import torch.distributed as dist
     import unet_amd
     from unet_amd.dp import DataParallelTrainer, KernelTimer
-    from oracle import ref_cpu
 
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
@@ -189,7 +218,7 @@ def main():
     model = unet_amd.UNet(3, 1).to(dev)
     trainer = DataParallelTrainer(model, lr=1e-3)
     # synthetic data of the ISIC2018 shape, a different shard per rank, resident in HBM
-    x, m = ref_cpu.synth_batch(args.batch, 3, args.size, args.size, seed_img=1234 + rank, seed_mask=4321 + rank)
+    x, m = synth_batch(args.batch, 3, args.size, args.size, seed_img=1234 + rank, seed_mask=4321 + rank)
     x, m = x.to(dev), m.to(dev)
 
     def barrier():

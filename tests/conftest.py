@@ -57,6 +57,7 @@ def run_two_ranks(out_dir, steps=3, world=2):
                 log=r.stdout[-3000:] + r.stderr[-4000:])
 
 
+@pytest.hookimpl(trylast=True)          # after the builtin -m / -k deselection: `items` is what will actually run
 def pytest_collection_modifyitems(config, items):
     config._dp_two_ranks = None
     if not any("test_dp_two_ranks_gpu" in it.nodeid for it in items) or not gpu_present():

@@ -49,3 +49,19 @@ def test_three_dimensional_masks_and_empty_batches():
     got = t.gather(torch.tensor([3, 1], device=DEV))
     assert torch.equal(got.cpu(), torch.from_numpy(masks)[[3, 1]].unsqueeze(1))
     assert t.gather(torch.empty(0, dtype=torch.int64, device=DEV)).shape == (0, 1, 8, 8)
+
+
+def test_uint8_arrays_keep_their_values():
+    """torch.FloatTensor(uint8 array) holds 0..255, not k/255 (training_utils.py:52-55): a uint8 {0,1} mask must come
+    out as {0.0, 1.0} and a uint8 image as its byte values."""
+    rng = np.random.default_rng(11)
+    images = rng.integers(0, 256, size=(5, 10, 12, 3), dtype=np.uint8)
+    masks = rng.integers(0, 2, size=(5, 10, 12, 1), dtype=np.uint8)
+    ds = DeviceDataset(images, masks, DEV)
+    assert ds.images.is_bytes and ds.masks.is_bytes
+    idx = torch.tensor([4, 0, 2])
+    x, m = ds.batch(idx)
+    want_x = torch.FloatTensor(images.astype(np.float32)).permute(0, 3, 1, 2)[idx]
+    want_m = torch.FloatTensor(masks.astype(np.float32)).permute(0, 3, 1, 2)[idx]
+    assert torch.equal(x.cpu(), want_x) and torch.equal(m.cpu(), want_m)
+    assert set(m.cpu().unique().tolist()) <= {0.0, 1.0} and float(x.max()) > 1.0

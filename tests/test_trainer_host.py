@@ -104,4 +104,39 @@ def test_byte_storage_is_chosen_only_when_it_is_exact():
     for v in (np.nan, -0.25, 1.5):
         bad = img.copy(); bad[0, 0, 0, 0] = v
         assert quantize_exact(bad)[1] is False
-    assert quantize_exact(k)[1] is True                                # bytes are taken as they are
+    assert quantize_exact(k)[1] is False                               # uint8 arrays are not rescaled (see DeviceTensorSet)
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus N` outside a launcher starts the N ranks as a child job and relays rank 0's one JSON
+    line and the exit code (here with a stand-in rank program on gloo: the bench itself needs GPUs)."""
+    import importlib.util
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = tmp_path / "rank_prog.py"
+    prog.write_text(
+        "import os, sys, json\n"
+        "import torch, torch.distributed as dist\n"
+        "dist.init_process_group('gloo')\n"
+        "t = torch.ones(1) * (dist.get_rank() + 1)\n"
+        "dist.all_reduce(t)\n"
+        "print('noise from rank', dist.get_rank(), flush=True)\n"
+        "if dist.get_rank() == 0:\n"
+        "    print(json.dumps({'n_gpus': dist.get_world_size(), 'sum': t.item(), 'argv': sys.argv[1:]}), flush=True)\n"
+        "dist.destroy_process_group()\n"
+        "sys.exit(3 if '--fail' in sys.argv else 0)\n")
+    driver = ("import sys; sys.path.insert(0, %r); import bench; "
+              "sys.exit(bench.launch_ranks(2, sys.argv[1:], script=%r))" % (root, str(prog)))
+    r = subprocess.run([sys.executable, "-c", driver, "--steps", "2"], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d == {"n_gpus": 2, "sum": 3.0, "argv": ["--steps", "2"]}
+    r = subprocess.run([sys.executable, "-c", driver, "--fail"], capture_output=True, text=True, timeout=240)
+    assert r.returncode != 0
+    # the launcher runs before torch is imported by the bench process itself
+    src = open(os.path.join(root, "bench.py")).read()
+    assert src.index("launch_ranks(args.gpus") < src.index("    import torch\n    import torch.distributed as dist")

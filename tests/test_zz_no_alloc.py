@@ -31,6 +31,13 @@ def _both(n, seed, scale):
     before = torch.cuda.memory_stats(DEV)["allocation.all.allocated"]
     _lib.call("uh_bce_logits_noalloc", n, x.data_ptr(), t.data_ptr(), scale, loss_b.data_ptr(), dx_b.data_ptr(), s)
     assert torch.cuda.memory_stats(DEV)["allocation.all.allocated"] == before
+    # torch's counters only see torch's allocator: a second, warmed-up call must also leave the DRIVER's free-byte count
+    # where it was (a hipMalloc / hipMallocAsync inside the entry point would move it)
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info(DEV)[0]
+    _lib.call("uh_bce_logits_noalloc", n, x.data_ptr(), t.data_ptr(), scale, loss_b.data_ptr(), dx_b.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info(DEV)[0] == free_before
     torch.cuda.synchronize()
     ref = torch.nn.functional.binary_cross_entropy_with_logits(x, t)
     return loss_a, dx_a, loss_b, dx_b, ref

@@ -1018,6 +1018,10 @@ extern "C" int uh_conv_gemm_ws(int B, int H, int W, const void* a, int a_cstride
     UH_REQUIRE(((N / 4 < o_cstride - o_coff) ? N / 4 : o_cstride - o_coff) % 4 == 0,
                "conv_gemm: transposed conv needs an output channel count that is a multiple of 4");
     UH_REQUIRE(T == 1, "conv_gemm: transposed conv is a T=1 GEMM");
+    // the pixel-shuffle epilogue steps its OUTPUT row index in 32 bits
+    UH_REQUIRE((long long)B * (2ll * H + 1) * (2ll * W + 1) < (1ll << 31),
+               "conv_gemm: transposed conv output has %lld rows, beyond the epilogue's 32-bit row arithmetic",
+               (long long)B * (2ll * H + 1) * (2ll * W + 1));
   } else {
     UH_REQUIRE(o_cstride >= o_coff + N, "conv_gemm: out view too narrow");
   }

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs p) {
         voff = a_voff;
       }
       const uint32_t lds_addr = (uint32_t)(uintptr_t)(UH_LDS char*)(smem + gi * 1024);
-      asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory");
+      asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory", "m0");
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad1_wide_kernel(WgradArgs p) {
                          (img & 1) * 128;
       const uint32_t voff = img < 2 ? dy_voff : a_voff;
       const uint32_t lds_addr = (uint32_t)(uintptr_t)(UH_LDS char*)(smem + gi * 1024);
-      asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory");
+      asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory", "m0");
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_col_kernel(WgradArgs p) {
   // prefetch; the waits for these loads are the explicit ones at the end of each stage.
   auto dma = [&](const char* base, uint32_t voff, int dst) {
     const uint32_t lds_addr = (uint32_t)(uintptr_t)(UH_LDS char*)(smem + dst);
-    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory", "m0");
   };
   // dY of the stage at pixel mb into buffer db; bands first .. 2 of it into their slots (rot + d) & 3
   auto issue = [&](long long mb, int db, int rot, int first) {

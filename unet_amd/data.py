@@ -15,15 +15,15 @@ import torch
 from . import _lib
 
 _LUT = (np.arange(256, dtype=np.float32) / np.float32(255.0)).astype(np.float32)     # the loaders' own expression
+_LUT_IDENTITY = np.arange(256, dtype=np.float32)     # torch.FloatTensor(uint8 array) keeps 0..255 as they are
 
 
 def quantize_exact(array, chunk=64):
-    """array [N,H,W,C] (or [N,H,W]) fp32/uint8 -> (uint8 array, True) if every value is _LUT[k] for some byte k
-    (uint8 input is taken as k itself, i.e. as the loaders' array before their /255), else (None, False).
-    Works through the array `chunk` items at a time, so the host never holds a second fp32 copy."""
+    """fp32 array [N,H,W,C] (or [N,H,W]) -> (uint8 array, True) if every value is _LUT[k] for some byte k, else
+    (None, False).  Works through the array `chunk` items at a time, so the host never holds a second fp32 copy.
+    (A uint8 array is not this function's business: DeviceTensorSet stores it as it is and converts k -> float(k),
+    which is what the reference's FloatTensor(array) does, training_utils.py:52-55.)"""
     a = np.asarray(array)
-    if a.dtype == np.uint8:
-        return a, True
     if a.dtype != np.float32:
         return None, False
     out = np.empty(a.shape, dtype=np.uint8)
@@ -51,11 +51,15 @@ class DeviceTensorSet:
             raise ValueError(f"expected [N,H,W,C] or [N,H,W], got shape {a.shape}")
         self.n, self.H, self.W, self.C = (int(v) for v in a.shape)
         self.device = torch.device(device)
-        q, exact = quantize_exact(a)
+        if a.dtype == np.uint8:
+            q, exact, table = a, True, _LUT_IDENTITY            # FloatTensor(uint8) = the byte values themselves
+        else:
+            q, exact = quantize_exact(a)
+            table = _LUT
         self.is_bytes = exact
         if exact:
             self.data = torch.from_numpy(np.ascontiguousarray(q)).to(self.device)
-            self.lut = torch.from_numpy(_LUT).to(self.device)
+            self.lut = torch.from_numpy(table).to(self.device)
         else:
             self.data = torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).to(self.device)
             self.lut = None

@@ -198,8 +198,11 @@ class DataParallelTrainer:
         self.collectives = joined and (self.world > 1 or os.environ.get("UNET_AMD_FORCE_COLLECTIVES") == "1")
         # the second stream takes its hardware queue before the process group's streams take theirs
         dev = next(model.parameters()).device
+        self._opt_stream = None
         if dev.type == "cuda":
             side_stream_for(dev)
+            if self.collectives:
+                self._opt_stream = side_stream_for(dev, "opt")
         if self.collectives:
             # same initial weights on every rank
             for p in model.parameters():
@@ -242,24 +245,32 @@ class DataParallelTrainer:
             self._adam_for_bucket(i, b)
 
     def _adam_for_bucket(self, i, b):
-        """Adam for a bucket as soon as its (averaged) gradients exist, on the engine's second stream, beside the rest
-        of the backward pass.  Nothing that backward still has to run reads fp32 parameters whose gradients are
-        complete: input gradients use the bf16 operands packed before, BatchNorm backward its saved scale."""
+        """Adam for a bucket as soon as its (averaged) gradients exist, beside the rest of the backward pass.  Nothing
+        that backward still has to run reads fp32 parameters whose gradients are complete: input gradients use the bf16
+        operands packed before, BatchNorm backward its saved scale.
+
+        Without collectives the update runs on the engine's second stream, behind the weight gradients that fill the
+        bucket.  With collectives it runs on a third stream, which is the one that waits for the bucket's all-reduce:
+        the second stream carries every later weight gradient and must never sit behind a collective."""
         side = self._run._side_stream() if (self._eager and self._run is not None) else None
         if side is None:
             return
         last = i == len(self.buckets.buckets) - 1
         lo = b["start"] & ~3                           # bucket boundaries are parameter boundaries: round both ends
         hi = self.optimizer.p.numel() if last else (b["end"] & ~3)   # down; the 0-3 elements cut off go with the next
-        side.wait_stream(torch.cuda.current_stream())  # gradients written on this stream (BatchNorm, biases)
-        with torch.cuda.stream(side):
-            w = b.get("work")
+        w = b.get("work")
+        if w is not None:
+            st = self._opt_stream                      # ordered behind the collective only (which is behind both
+        else:                                          # streams' writes: see _on_ready)
+            st = side
+            side.wait_stream(torch.cuda.current_stream())  # gradients written on this stream (BatchNorm, biases)
+        with torch.cuda.stream(st):
             if w is not None:
-                w.wait()                               # the second stream waits for the collective
+                w.wait()                               # the third stream waits for the collective
             if not self._adam_begun:
                 self.optimizer.begin_step()
                 self._adam_begun = True
-            self.optimizer.step_range(lo, hi, side.cuda_stream)
+            self.optimizer.step_range(lo, hi, st.cuda_stream)
         b["adam"] = True
 
     def train_step(self, images, masks, step_optimizer=True):
@@ -288,6 +299,8 @@ class DataParallelTrainer:
             w = b.pop("work", None)
             if w is not None:
                 w.wait()                     # current stream waits for the collective
+        if self._opt_stream is not None:     # and for the bucket-wise optimizer updates behind the collectives
+            torch.cuda.current_stream().wait_stream(self._opt_stream)
         if step_optimizer:
             if self._adam_begun:                 # done bucket by bucket beside backward (joined at its end)
                 missing = [b for b in self.buckets.buckets if not b.get("adam")]

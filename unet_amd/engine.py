@@ -85,8 +85,9 @@ def ranged(label):
     return deco
 
 
-def side_stream_for(device):
-    """The second stream of a device (one per process and device).
+def side_stream_for(device, which="wgrad"):
+    """A further stream of a device (one per process, device and `which`): "wgrad" is the engine's second stream,
+    "opt" the data-parallel trainer's third (collective waits + optimizer).
 
     It should own a hardware queue.  A process has few hardware queues (GPU_MAX_HW_QUEUES, 4 by default) and HIP binds a
     stream to one of them, in turn, when the stream is first used; a second stream first used after a process group
@@ -98,10 +99,10 @@ def side_stream_for(device):
     was not served any more and the step never finished."""
     device = torch.device(device)
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    st = _SIDE_STREAMS.get(idx)
+    st = _SIDE_STREAMS.get((idx, which))
     if st is None:
         prio = int(os.environ.get("UNET_AMD_SIDE_PRIORITY", "0"))
-        st = _SIDE_STREAMS[idx] = torch.cuda.Stream(device=torch.device("cuda", idx), priority=prio)
+        st = _SIDE_STREAMS[(idx, which)] = torch.cuda.Stream(device=torch.device("cuda", idx), priority=prio)
         with torch.cuda.stream(st):
             torch.zeros(1, device=torch.device("cuda", idx))      # first use: binds the hardware queue now
         st.synchronize()
