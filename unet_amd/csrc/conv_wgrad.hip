@@ -14,6 +14,10 @@
 // workspace slab and summed by uh_wgrad_reduce (deterministic, no atomics).
 #include "common.h"
 #include <cstdlib>
+// The LDS-DMA statements below write M0 and name it as clobbered, so that the compiler's own M0 set-up (it merges
+// identical M0 initialisations when nothing between them modifies the register) never assumes a value across them.
+// M0 is a reserved register, for which clang warns on every clobber list; the declaration is intended.
+#pragma clang diagnostic ignored "-Winline-asm"
 
 struct WgradArgs {
   const char* dY;
