@@ -192,9 +192,10 @@ def test_soft_skeleton_order_relations_at_full_size():
     assert n == p.numel()
 
 
-@pytest.mark.parametrize("b,hw", [(2, 512), (1, 1024)])
+@pytest.mark.parametrize("b,hw", [(2, 512), (1, 1024), (16, 512), (4, 1024)])
 def test_unet_large_images(b, hw):
-    """BASELINE configs[3] and [4] image sizes (512^2 training, 1024^2 training + batch-1 inference), small batches:
+    """BASELINE configs[3] and [4] image sizes (512^2 training, 1024^2 training + batch-1 inference), on small batches
+    and on the batches those configurations train with per GPU (16 at 512^2, 4 at 1024^2):
     a training step is deterministic and finite, and eval-mode inference of one image does not depend on the batch
     it arrives in (to rounding)."""
     torch.manual_seed(3)
@@ -212,6 +213,10 @@ def test_unet_large_images(b, hw):
     for n in g1:
         assert torch.isfinite(g1[n]).all(), n
         assert torch.equal(g1[n], g2[n]), n
+        if n.endswith(".bias") and n.startswith("conv"):       # in front of train-mode BatchNorm: exactly zero
+            assert g1[n].abs().max().item() == 0.0, n
+        else:
+            assert g1[n].abs().max().item() > 0, n
     model.eval()
     with torch.no_grad():
         full = model(x)

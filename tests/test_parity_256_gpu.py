@@ -1,6 +1,6 @@
 """Element-wise parity with the CPU oracle at the size the benchmark runs (3x256x256; BASELINE configs[1] and [2]) on
-batches the oracle finishes in seconds: U-Net train step (batch 4, BCE) and eval forward (batch 8), LUNeXt train step
-with the clDice loss (batch 4).  Every BatchNorm layer then sees >= 1024 samples per channel.
+batches the oracle finishes in seconds: U-Net train step (batch 4, BCE; also batch 2 at 3x512x512, the image size of
+configs[3]) and eval forward (batch 8), LUNeXt train step with the clDice loss (batch 4).  Every BatchNorm layer then sees >= 1024 samples per channel.
 
 Bounds against the fp32 oracle: logits within 2 % of max |logit| and cosine >= 0.999; loss within 1 %; parameter
 gradients of the last decoder stage (the first layers of the backward pass) cosine >= 0.99 and norm within 2 %.
@@ -73,7 +73,9 @@ def check_grads(model, ref, emu, last_stage, zero_grad_names=()):
     return worst
 
 
-def test_unet_train_step_batch4_256():
+@pytest.mark.parametrize("batch,size", [(4, SIZE), (2, 512)])
+def test_unet_train_step_elementwise(batch, size):
+    """batch 4 at 256^2 (BASELINE configs[1]'s image size) and batch 2 at 512^2 (configs[3]'s), same bounds"""
     torch.manual_seed(0)
     ref = ref_cpu.RefUNet(3, 1).train()
     model = unet_amd.UNet(3, 1)
@@ -81,7 +83,7 @@ def test_unet_train_step_batch4_256():
     model = model.to(DEV).train()
     emu = emu_bf16.EmuUNet(3, 1).train()
     emu.load_state_dict(ref.state_dict())
-    x, m = ref_cpu.synth_batch(4, 3, SIZE, SIZE)
+    x, m = ref_cpu.synth_batch(batch, 3, size, size)
     crit = nn.BCEWithLogitsLoss()
     want = ref(x)
     loss_ref = crit(want, m)
@@ -91,7 +93,7 @@ def test_unet_train_step_batch4_256():
     loss = crit(logits, m.to(DEV))
     loss.backward()
     torch.cuda.synchronize()
-    check_logits(logits, want, "U-Net train")
+    check_logits(logits, want, f"U-Net train, batch {batch}, {size}^2")
     assert abs(loss.item() - loss_ref.item()) <= 1e-2 * loss_ref.item()
     zero = {n for n, _ in model.named_parameters() if n.endswith(".bias") and n.startswith("conv")}
     print("worst cosine:", check_grads(model, ref, emu, ("conv_up4", "bn_up4", "final_conv"), zero))
