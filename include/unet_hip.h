@@ -227,6 +227,13 @@ int uh_colsum_finalize(const float* partial, int P, int C, int fold, float* out,
 /* ---- 1x1 segmentation head Conv2d(C -> OC) (unet.py:173; lunext.py:257), fp32 NCHW logits ------ */
 int uh_head_fwd(int B, int H, int W, int C, int OC, const void* a, int a_cstride, int a_coff,
                 const float* w, const float* bias, float* logits_nchw, uh_stream s);
+/* The one-channel head in evaluation (trainer/k_fold.py:281-290, test_helper/utils.py:124-131): the launch that makes
+ * the logits also binarises them (sigmoid(x) > 0.5, fp32) and adds tp, tn, fp, fn against `mask` ([B,1,H,W] fp32) to
+ * counts[plane][4] (int64; one plane per image if per_sample, else one for the batch).  logits_nchw may be NULL when
+ * only the counts are wanted.  Counts equal uh_confusion_counts over uh_head_fwd's logits exactly. */
+int uh_head_fwd_counts(int B, int H, int W, int C, const void* a, int a_cstride, int a_coff, const float* w,
+                       const float* bias, float* logits_nchw, const float* mask, int per_sample, long long* counts,
+                       uh_stream s);
 int uh_head_bwd_parts(int B, int H, int W, int C);
 int uh_head_bwd(int B, int H, int W, int C, int OC, const void* a, int a_cstride, int a_coff,
                 const float* w, const float* dlogits_nchw,
@@ -319,6 +326,15 @@ int uh_nchw_to_c8(int B, int Cin, int H, int W, const float* x, void* out, int o
  *   g' = g + wd*p; m += (1-b1)(g'-m); v = b2 v + (1-b2) g'^2; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps) */
 int uh_adam_step(long long n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2,
                  float eps, float weight_decay, int step, uh_stream s);
+/* The same step under torch.amp.GradScaler (scaler.step(optimizer); training_utils.py:153-155): grad_scale and found_inf
+ * are DEVICE scalars (either may be NULL).  The gradient is read as g * (1 / *grad_scale), so no unscale pass over the
+ * gradients is needed, and when *found_inf != 0 the launch changes nothing (the skipped step of GradScaler).  A
+ * skipped step is not counted, which the host cannot know without reading found_inf back: step_dev, when not NULL, is
+ * a device scalar holding the count of this step (the caller adds 1 - *found_inf to it before the launch) and
+ * replaces `step` in the bias corrections. */
+int uh_adam_step_amp(long long n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2,
+                     float eps, float weight_decay, int step, const float* grad_scale, const float* found_inf,
+                     const float* step_dev, uh_stream s);
 
 /* ---- nn.BCEWithLogitsLoss() as the trainer builds it (trainer/training_utils.py:105: mean reduction, no weights),
  * forward and backward in one pass over fp32 logits and targets of n elements:

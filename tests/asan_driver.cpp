@@ -60,6 +60,8 @@ static void walk() {
   refuse(uh_conv_wgrad(1, 8, 8, p, 64, 0, 64, p, 64, 0, 64, 3, (float*)p, nullptr), "T=3");
   refuse(uh_adam_step(10, (float*)p, (float*)p, (float*)p, (float*)p, 1e-3f, 0.9f, 0.999f, 1e-8f, 0.f, 1, nullptr),
          "multiple of 4");
+  refuse(uh_adam_step_amp(8, (float*)p, (float*)p, (float*)p, nullptr, 1e-3f, 0.9f, 0.999f, 1e-8f, 0.f, 1, nullptr, nullptr,
+                          nullptr, nullptr), "bad arguments");
   refuse(uh_bce_logits(0, (float*)p, (float*)p, 1.f, (float*)p, nullptr, p, 16, nullptr), nullptr);
   refuse(uh_bce_logits(4096, (float*)p, (float*)p, 1.f, (float*)p, nullptr, p, 1, nullptr), "workspace");
   refuse(uh_bce_logits_noalloc((1ll << 32) + 1, (float*)p, (float*)p, 1.f, (float*)p, nullptr, nullptr),

@@ -89,3 +89,27 @@ def test_weight_gradients_do_not_wait_for_collectives(monkeypatch, tmp_path):
         assert trainer.optimizer.steps == 2
     finally:
         dist.destroy_process_group()
+
+
+def test_train_step_under_grad_scaler_equals_the_unscaled_step():
+    """train_step(scaler=GradScaler) (training_utils.py:153-155): the loss gradient is scaled by 2^16, the optimizer
+    unscales inside its kernel.  Scaling by a power of two commutes with every bf16 / fp32 rounding of the backward
+    pass, so two steps end at the parameters of the unscaled run (up to the reciprocal's rounding: none here)."""
+    import unet_amd
+    from unet_amd.dp import DataParallelTrainer
+    dev = torch.device("cuda", 0)
+    x = torch.rand(4, 3, 32, 32, device=dev)
+    m = (torch.rand(4, 1, 32, 32, device=dev) > 0.5).float()
+    out = []
+    for amp in (False, True):
+        torch.manual_seed(0)
+        model = unet_amd.UNet(3, 1).to(dev)
+        trainer = DataParallelTrainer(model, lr=1e-3, standalone=True)
+        scaler = torch.amp.GradScaler("cuda") if amp else None
+        losses = [trainer.train_step(x, m, scaler=scaler).item() for _ in range(2)]
+        out.append((losses, trainer.optimizer.p.clone()))
+        if amp:
+            assert scaler.get_scale() == 65536.0 and trainer.optimizer._steps_dev.item() == 2.0
+    assert out[0][0] == out[1][0]
+    torch.testing.assert_close(out[0][1], out[1][1], rtol=1e-6, atol=1e-8)
+    assert not torch.equal(out[0][1], torch.zeros_like(out[0][1]))

@@ -208,3 +208,33 @@ def test_train_kfold_single_process(tmp_path):
     if max(r["Dice"] for r in rec) > 0:
         assert set(best) == {"dice", "iou", "precision", "recall", "accuracy", "f1"}
         ref_cpu.RefUNet(3, 1).load_state_dict(torch.load(path, map_location="cpu", weights_only=True))
+
+
+@pytest.mark.parametrize("b,hw,per_sample", [(5, 48, False), (5, 48, True), (1, 1024, True), (8, 256, False)])
+def test_head_counts_equal_confusion_counts_of_the_same_logits(b, hw, per_sample):
+    """predict_counts (uh_head_fwd_counts: binarise + tally inside the head launch, k_fold.py:289-290) against the
+    two-pass form it replaces (uh_head_fwd, then uh_confusion_counts): logits and integer counts bit-exact."""
+    torch.manual_seed(8)
+    model = unet_amd.UNet(3, 1).to(DEV).eval()
+    g = torch.Generator().manual_seed(hw + b)
+    x = torch.rand(b, 3, hw, hw, generator=g).to(DEV)
+    m = (torch.rand(b, 1, hw, hw, generator=g) > 0.4).float()
+    m[0, 0, :2, :] = 0.5                                    # mask values outside {0, 1} fall into no class
+    m = m.to(DEV)
+    with torch.no_grad():
+        model.final_conv.bias -= model(x).median()          # both predicted classes occur
+        logits = model(x)
+    planes = b if per_sample else 1
+    want = torch.zeros(planes, 4, dtype=torch.int64, device=DEV)
+    trainer.confusion_counts(logits, m, want.view(-1) if not per_sample else want, per_sample=per_sample)
+    got = torch.full((planes, 4), 3, dtype=torch.int64, device=DEV)           # the launch ADDS to what is there
+    out = model.predict_counts(x, m, got.view(-1) if not per_sample else got, per_sample=per_sample, return_logits=True)
+    assert torch.equal(out, logits)
+    assert torch.equal(got - 3, want)
+    assert want[:, 0].sum().item() > 0 and want[:, 1].sum().item() > 0
+    assert int(want.sum()) == b * hw * hw - 2 * hw          # the two rows of 0.5 are in no class
+    again = torch.zeros(planes, 4, dtype=torch.int64, device=DEV)
+    assert model.predict_counts(x, m, again.view(-1) if not per_sample else again, per_sample=per_sample) is None
+    assert torch.equal(again, want)
+    with pytest.raises(ValueError):
+        model.predict_counts(x, m, torch.zeros(3, dtype=torch.int64, device=DEV))

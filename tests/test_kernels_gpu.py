@@ -982,3 +982,61 @@ def test_gate8_forward_backward(B, H, W, C):
     for j in range(3):
         close(gw[64 * j:64 * j + 64].view(8, 8)[:C, :C], Ws[j].grad, 2e-3, f"gate8 backward: dW{j + 1}")
         close(gw[192 + 8 * j:192 + 8 * j + C], bs[j].grad, 2e-3, f"gate8 backward: db{j + 1}")
+
+
+def test_flat_adam_under_grad_scaler_matches_torch():
+    """scaler.step(optimizer); scaler.update() (training_utils.py:153-155) with FlatAdam, which unscales inside its Adam
+    kernel and skips the step on an inf (uh_adam_step_amp), against torch.amp.GradScaler + torch.optim.Adam on the same
+    scaled gradients: steps 1-2 clean, step 3 carries an inf (skipped by both, scale halved), step 4 clean again, so the
+    bias corrections must count three steps, not four."""
+    import torch.nn as nn
+    from unet_amd.dp import FlatAdam
+
+    class Tiny(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = nn.Parameter(torch.randn(37, 5))
+            self.b = nn.Parameter(torch.randn(1001))
+
+    class Flat:                      # the two attributes of GradBuckets that FlatAdam uses
+        def __init__(self, model):
+            self.order = [n for n, _ in model.named_parameters()]
+            total = sum(p.numel() for p in model.parameters())
+            self.flat = torch.zeros((total + 3) // 4 * 4, device=DEV)
+            off = 0
+            for p in model.parameters():
+                p.grad = self.flat[off:off + p.numel()].view(p.shape)
+                off += p.numel()
+
+    torch.manual_seed(5)
+    mine = Tiny().to(DEV)
+    ref = Tiny().to(DEV)
+    ref.load_state_dict(mine.state_dict())
+    opt = FlatAdam(mine, Flat(mine), lr=1e-2)
+    ropt = torch.optim.Adam(ref.parameters(), lr=1e-2)
+    sc, rsc = torch.amp.GradScaler("cuda", init_scale=1024.0), torch.amp.GradScaler("cuda", init_scale=1024.0)
+    g = torch.Generator(device=DEV).manual_seed(9)
+    for step in range(4):
+        scale = rsc.get_scale()
+        assert sc.get_scale() == scale
+        before = [p.detach().clone() for p in mine.parameters()]
+        for p, q in zip(mine.parameters(), ref.parameters()):
+            grad = torch.randn(p.shape, device=DEV, generator=g) * scale           # what scaled backward leaves
+            if step == 2 and p.dim() == 1:
+                grad[17] = float("inf")
+            p.grad.copy_(grad)
+            q.grad = grad.clone()
+        sc.scale(torch.ones((), device=DEV))            # initialises the scaler's device state, as scale(loss) does
+        rsc.scale(torch.ones((), device=DEV))
+        sc.step(opt)
+        sc.update()
+        rsc.step(ropt)
+        rsc.update()
+        for p, q, b in zip(mine.parameters(), ref.parameters(), before):
+            if step == 2:
+                assert torch.equal(p, b)                 # skipped as a whole
+            torch.testing.assert_close(p, q, rtol=2e-6, atol=2e-7)
+    assert sc.get_scale() == rsc.get_scale() == 512.0
+    assert opt._steps_dev.item() == 3.0
+    # the flat gradient the scaler walked is the one buffer: its inf check saw every parameter's gradient
+    assert opt.param_groups[0]["params"][0].grad.data_ptr() == opt.g.data_ptr()

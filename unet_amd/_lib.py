@@ -59,6 +59,7 @@ SIGNATURES = {
     "uh_colsum": (I, [L, I, P, I, I, P, P]),
     "uh_colsum_finalize": (I, [P, I, I, I, P, I, P]),
     "uh_head_fwd": (I, [I, I, I, I, I, P, I, I, P, P, P, P]),
+    "uh_head_fwd_counts": (I, [I, I, I, I, P, I, I, P, P, P, P, I, P, P]),
     "uh_head_bwd_parts": (I, [I, I, I, I]),
     "uh_head_bwd_bnstat": (I, [I, I, I, I, I, P, I, I, P, P, P, I, I, P, P, I, I, P, P, P, P, P, P]),
     "uh_bn_relu_apply_pool2": (I, [I, I, I, I, P, I, I, P, P, P, I, I, P, I, I, P]),
@@ -88,6 +89,7 @@ SIGNATURES = {
     "uh_gate8_bwd": (I, [L, I, P, I, I, P, I, I, P, I, I, P, P, I, I, P, I, I, P, P]),
     "uh_nchw_to_c8": (I, [I, I, I, I, P, P, I, I, P]),
     "uh_adam_step": (I, [L, P, P, P, P, F, F, F, F, F, I, P]),
+    "uh_adam_step_amp": (I, [L, P, P, P, P, F, F, F, F, F, I, P, P, P, P]),
     "uh_gather_batch_u8": (I, [I, I, I, I, I, P, P, P, P, P]),
     "uh_gather_batch_f32": (I, [I, I, I, I, I, P, P, P, P]),
     "uh_confusion_counts": (I, [I, L, P, P, P, P]),

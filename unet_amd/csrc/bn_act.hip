@@ -595,14 +595,24 @@ extern "C" int uh_maxpool2_bwd_bnstat(int B, int H, int W, int C, const void* a,
 
 // ---- 1x1 head: logits[b][oc][y][x] = sum_c a[m][c]*w[oc][c] + bias[oc] ---------------------------------
 // C/8 lanes share one pixel (C/8 a power of two <= 64) and combine with xor-shuffles.
+// COUNTS: the launch also binarises its logits (sigmoid(x) > 0.5 in fp32, the rule of trainer/k_fold.py:289-290) and
+// tallies tp / tn / fp / fn against a mask, per plane = blockIdx.y (one plane per image, or one for the whole batch):
+// the evaluation loop then reads neither the logits nor the mask a second time.  The logit arithmetic is the same
+// instruction sequence with and without COUNTS, so the tallies equal those of uh_confusion_counts over the logits of
+// uh_head_fwd bit for bit.
+template <bool COUNTS>
 __global__ __launch_bounds__(256) void head_fwd_kernel(int B, int H, int W, int C, int OC, const char* __restrict__ a,
                                                        int a_cs, int a_co, const float* __restrict__ w,
-                                                       const float* __restrict__ bias, float* __restrict__ logits) {
+                                                       const float* __restrict__ bias, float* __restrict__ logits,
+                                                       long long plane_pix, const float* __restrict__ mask,
+                                                       unsigned long long* __restrict__ counts) {
   const int cpr = C / 8, ppi = 256 / cpr;
   const int pp = threadIdx.x / cpr, cc = threadIdx.x % cpr;
   const int Wp = W + 1, Hp = H + 1;
-  const long long npix = (long long)B * H * W;
-  for (long long base = (long long)blockIdx.x * ppi; base < npix; base += (long long)gridDim.x * ppi) {
+  const long long first = (long long)blockIdx.y * plane_pix;
+  const long long npix = first + plane_pix;
+  unsigned cnt[4] = {0u, 0u, 0u, 0u};
+  for (long long base = first + (long long)blockIdx.x * ppi; base < npix; base += (long long)gridDim.x * ppi) {
     const long long pix = base + pp;
     const bool ok = pix < npix;
     float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -621,7 +631,37 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(int B, int H, int W, int 
 #pragma unroll
       for (int j = 0; j < 8; ++j) s += v[j] * w[oc * C + cc * 8 + j];
       for (int o = cpr >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-      if (ok && cc == 0) logits[((b * OC + oc) * H + y) * W + x] = s + (bias ? bias[oc] : 0.f);
+      if (ok && cc == 0) {
+        const float lg = s + (bias ? bias[oc] : 0.f);
+        const long long at = ((b * OC + oc) * H + y) * W + x;
+        if (logits) logits[at] = lg;
+        if constexpr (COUNTS) {                       // OC == 1 here: `at` is also the mask's index
+          const float mk = mask[at];
+          const bool p = 1.0f / (1.0f + expf(-lg)) > 0.5f;
+          const bool t1 = mk == 1.0f, t0 = mk == 0.0f;
+          cnt[0] += (p && t1);
+          cnt[1] += (!p && t0);
+          cnt[2] += (p && t0);
+          cnt[3] += (!p && t1);
+        }
+      }
+    }
+  }
+  if constexpr (COUNTS) {
+    __shared__ unsigned red[4][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      unsigned t = cnt[k];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+      if (lane == 0) red[wave][k] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+      const unsigned long long t = (unsigned long long)red[0][threadIdx.x] + red[1][threadIdx.x] +
+                                   red[2][threadIdx.x] + red[3][threadIdx.x];
+      if (t) atomicAdd(&counts[(long long)blockIdx.y * 4 + threadIdx.x], t);    // integer adds commute
     }
   }
 }
@@ -636,9 +676,28 @@ extern "C" int uh_head_fwd(int B, int H, int W, int C, int OC, const void* a, in
   const int ppi = 256 / (C / 8);
   long long blocks = (npix + ppi - 1) / ppi;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, B, H, W, C, OC,
-                     (const char*)a, a_cstride, a_coff, w, bias, logits);
+  hipLaunchKernelGGL(head_fwd_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, B, H, W, C, OC,
+                     (const char*)a, a_cstride, a_coff, w, bias, logits, npix, nullptr, nullptr);
   return uh_check_launch("head_fwd");
+}
+
+extern "C" int uh_head_fwd_counts(int B, int H, int W, int C, const void* a, int a_cstride, int a_coff, const float* w,
+                                  const float* bias, float* logits, const float* mask, int per_sample,
+                                  long long* counts, uh_stream s) {
+  UH_REQUIRE(B > 0 && H > 0 && W > 0 && a && w && mask && counts, "head_fwd_counts: bad arguments");
+  UH_REQUIRE(head_c_ok(C), "head_fwd_counts: C=%d must be a power of two in [8,512]", C);
+  UH_REQUIRE(!per_sample || B <= 65535, "head_fwd_counts: at most 65535 images per launch with per-sample counts");
+  const int planes = per_sample ? B : 1;
+  const long long plane_pix = (long long)B * H * W / planes;
+  UH_REQUIRE(plane_pix < (1ll << 40), "head_fwd_counts: plane of %lld pixels too large", plane_pix);
+  const int ppi = 256 / (C / 8);
+  long long blocks = (plane_pix + ppi - 1) / ppi;
+  const long long want = (4096 + planes - 1) / planes;      // a thread tallies in 32 bits: its share stays far below 2^32
+  if (blocks > want) blocks = want;
+  hipLaunchKernelGGL(head_fwd_kernel<true>, dim3((unsigned)blocks, (unsigned)planes), dim3(256), 0, (hipStream_t)s, B, H, W,
+                     C, 1, (const char*)a, a_cstride, a_coff, w, bias, logits, plane_pix, mask,
+                     reinterpret_cast<unsigned long long*>(counts));
+  return uh_check_launch("head_fwd_counts");
 }
 
 // backward: da[m][c] = sum_oc dl[oc][m]*w[oc][c] (0 on pads); partial[blk][oc][C+1] = (sum_m dl*a[m][c], sum_m dl)

@@ -246,9 +246,25 @@ extern "C" int uh_depth_to_space2_add(int B, int H, int W, int C, int bigH, int 
 // ---- Adam over one flat parameter buffer (torch.optim.Adam defaults, trainer/training_utils.py:107) ------------
 // p, g, m, v: n floats each.  One pass: 16 B read + 12 B written per parameter; the 82 parameter tensors of
 // the U-Net are views of one buffer, so this is one launch instead of a multi-tensor sweep.
+// AMP = true: the gradient is divided by *grad_scale on the way in, and the whole launch does nothing when *found_inf
+// is non-zero (what torch.amp.GradScaler.step asks of an optimizer that takes over unscaling and skipping).
+template <bool AMP>
 __global__ __launch_bounds__(256) void adam_kernel(long long n4, float4* __restrict__ p, const float4* __restrict__ g,
                                                    float4* __restrict__ m, float4* __restrict__ v, float b1, float b2,
-                                                   float step_size, float inv_sqrt_bc2, float eps, float wd) {
+                                                   float step_size, float inv_sqrt_bc2, float eps, float wd,
+                                                   const float* __restrict__ grad_scale,
+                                                   const float* __restrict__ found_inf,
+                                                   const float* __restrict__ step_dev, float lr, float b1d, float b2d) {
+  float inv_scale = 1.f;
+  if constexpr (AMP) {
+    if (found_inf && *found_inf != 0.f) return;
+    if (grad_scale) inv_scale = (float)(1.0 / (double)*grad_scale);       // GradScaler's own reciprocal
+    if (step_dev) {                        // the step count lives on the device (skipped steps are not counted)
+      const double t = (double)*step_dev;
+      step_size = (float)((double)lr / (1.0 - pow((double)b1d, t)));
+      inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)b2d, t)));
+    }
+  }
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
     float4 pp = p[i], gg = g[i], mm = m[i], vv = v[i];
     float* pf = (float*)&pp;
@@ -257,7 +273,8 @@ __global__ __launch_bounds__(256) void adam_kernel(long long n4, float4* __restr
     float* vf = (float*)&vv;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float gr = gf[j] + wd * pf[j];
+      const float gu = AMP ? gf[j] * inv_scale : gf[j];
+      const float gr = gu + wd * pf[j];
       mf[j] = mf[j] + (1.f - b1) * (gr - mf[j]);                 // lerp, as torch's fused kernel
       vf[j] = b2 * vf[j] + (1.f - b2) * gr * gr;
       const float denom = sqrtf(vf[j]) * inv_sqrt_bc2 + eps;
@@ -269,15 +286,33 @@ __global__ __launch_bounds__(256) void adam_kernel(long long n4, float4* __restr
   }
 }
 
-extern "C" int uh_adam_step(long long n, float* p, const float* g, float* m, float* v, float lr, float beta1,
-                            float beta2, float eps, float weight_decay, int step, uh_stream s) {
+static int adam_launch(long long n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2,
+                       float eps, float weight_decay, int step, const float* grad_scale, const float* found_inf,
+                       const float* step_dev, bool amp, uh_stream s) {
   UH_REQUIRE(n > 0 && n % 4 == 0 && p && g && m && v && step >= 1, "adam_step: bad arguments (n must be a multiple of 4)");
   UH_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam_step: buffers must be 16-byte aligned");
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
   const long long n4 = n / 4;
   long long blocks = (n4 + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, n4, (float4*)p, (const float4*)g,
-                     (float4*)m, (float4*)v, beta1, beta2, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), eps, weight_decay);
+  if (amp)
+    hipLaunchKernelGGL(adam_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, n4, (float4*)p,
+                       (const float4*)g, (float4*)m, (float4*)v, beta1, beta2, (float)(lr / bc1),
+                       (float)(1.0 / sqrt(bc2)), eps, weight_decay, grad_scale, found_inf, step_dev, lr, beta1, beta2);
+  else
+    hipLaunchKernelGGL(adam_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, n4, (float4*)p,
+                       (const float4*)g, (float4*)m, (float4*)v, beta1, beta2, (float)(lr / bc1),
+                       (float)(1.0 / sqrt(bc2)), eps, weight_decay, nullptr, nullptr, nullptr, lr, beta1, beta2);
   return uh_check_launch("adam_step");
+}
+
+extern "C" int uh_adam_step(long long n, float* p, const float* g, float* m, float* v, float lr, float beta1,
+                            float beta2, float eps, float weight_decay, int step, uh_stream s) {
+  return adam_launch(n, p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, nullptr, nullptr, nullptr, false, s);
+}
+
+extern "C" int uh_adam_step_amp(long long n, float* p, const float* g, float* m, float* v, float lr, float beta1,
+                                float beta2, float eps, float weight_decay, int step, const float* grad_scale,
+                                const float* found_inf, const float* step_dev, uh_stream s) {
+  return adam_launch(n, p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale, found_inf, step_dev, true, s);
 }

@@ -108,7 +108,14 @@ class GradBuckets:
 
 class FlatAdam:
     """torch.optim.Adam(model.parameters(), lr) (training_utils.py:107) as one kernel launch: the parameters are
-    re-pointed into one flat fp32 buffer laid out like the gradient buckets, so p, g, m, v are four flat arrays."""
+    re-pointed into one flat fp32 buffer laid out like the gradient buckets, so p, g, m, v are four flat arrays.
+
+    Under torch.amp.GradScaler (training_utils.py:117,153-155) `scaler.step(optimizer)` works as it does with torch's
+    own fused optimizers: the scaler sees ONE parameter (the flat buffer, whose .grad is the flat gradient), so its
+    inf check is one launch, and because of _step_supports_amp_scaling it leaves unscaling and the skipped step to
+    step(), which folds both into the Adam kernel (uh_adam_step_amp): no unscale pass over the gradients."""
+
+    _step_supports_amp_scaling = True
 
     def __init__(self, model, buckets, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         self.model = model
@@ -118,6 +125,7 @@ class FlatAdam:
         self.m = torch.zeros_like(self.g)
         self.v = torch.zeros_like(self.g)
         self.steps = 0
+        self._steps_dev = None             # device-side count of the steps actually taken (AMP: skipped ones excluded)
         params = dict(model.named_parameters())
         off = 0
         with torch.no_grad():
@@ -127,19 +135,52 @@ class FlatAdam:
                 view.copy_(q.data)
                 q.data = view                      # the module's parameter now lives in the flat buffer
                 off += q.numel()
+        flat = nn.Parameter(self.p, requires_grad=False)
+        flat.grad = self.g
+        self.param_groups = [{"params": [flat], "lr": lr}]     # what GradScaler walks for its inf check
 
     def step(self):
-        self.begin_step()
-        self.step_range(0, self.p.numel(), torch.cuda.current_stream(self.p.device).cuda_stream)
+        """One Adam step over the whole buffer.  When a GradScaler has left `grad_scale` / `found_inf` on this object
+        (it does so around the call, for optimizers with _step_supports_amp_scaling), the gradient is unscaled inside
+        the kernel and the step does nothing if an inf / NaN was found."""
+        grad_scale, found_inf = getattr(self, "grad_scale", None), getattr(self, "found_inf", None)
+        stream = torch.cuda.current_stream(self.p.device).cuda_stream
+        if grad_scale is None and found_inf is None:
+            self.begin_step()
+            self.step_range(0, self.p.numel(), stream)
+        else:
+            self.step_amp(grad_scale, found_inf, stream)
         self.finish_step()
+
+    def step_amp(self, grad_scale, found_inf, stream):
+        """grad_scale, found_inf: fp32 scalars on the device (either may be None)"""
+        if self._steps_dev is None:
+            self._steps_dev = torch.full((1,), float(self.steps), dtype=torch.float32, device=self.p.device)
+        if found_inf is not None:
+            self._steps_dev.add_(1.0 - found_inf.reshape(1).to(self._steps_dev))     # a skipped step is not counted
+        else:
+            self._steps_dev.add_(1.0)
+        self.steps += 1                            # host-side count: upper bound, only used without a device count
+        _lib.call("uh_adam_step_amp", self.p.numel(), self.p.data_ptr(), self.g.data_ptr(), self.m.data_ptr(),
+                  self.v.data_ptr(), self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.steps,
+                  None if grad_scale is None else grad_scale.data_ptr(),
+                  None if found_inf is None else found_inf.data_ptr(), self._steps_dev.data_ptr(), stream)
 
     # the same step in pieces (a bucket at a time, as its gradients arrive): begin_step, step_range..., finish_step
     def begin_step(self):
         self.steps += 1
+        if self._steps_dev is not None:
+            self._steps_dev.add_(1.0)
 
     def step_range(self, lo, hi, stream):
         """elements [lo, hi) of the flat buffers; lo and hi multiples of 4"""
         if hi > lo:
+            if self._steps_dev is not None:        # steps have been skipped before: the device count is the true one
+                _lib.call("uh_adam_step_amp", hi - lo, self.p.data_ptr() + 4 * lo, self.g.data_ptr() + 4 * lo,
+                          self.m.data_ptr() + 4 * lo, self.v.data_ptr() + 4 * lo, self.lr, self.betas[0],
+                          self.betas[1], self.eps, self.weight_decay, self.steps, None, None,
+                          self._steps_dev.data_ptr(), stream)
+                return
             _lib.call("uh_adam_step", hi - lo, self.p.data_ptr() + 4 * lo, self.g.data_ptr() + 4 * lo,
                       self.m.data_ptr() + 4 * lo, self.v.data_ptr() + 4 * lo, self.lr, self.betas[0], self.betas[1],
                       self.eps, self.weight_decay, self.steps, stream)
@@ -273,12 +314,18 @@ class DataParallelTrainer:
             self.optimizer.step_range(lo, hi, st.cuda_stream)
         b["adam"] = True
 
-    def train_step(self, images, masks, step_optimizer=True):
-        """images [b,C,H,W] fp32, masks [b,1,H,W] on this rank's device.  Returns the local loss (0-dim tensor)."""
+    def train_step(self, images, masks, step_optimizer=True, scaler=None):
+        """images [b,C,H,W] fp32, masks [b,1,H,W] on this rank's device.  Returns the local loss (0-dim tensor).
+
+        scaler: a torch.amp.GradScaler, used as the reference's loop uses it (training_utils.py:153-155:
+        scaler.scale(loss).backward(); scaler.step(optimizer); scaler.update()): the backward pass is seeded with the
+        scaled loss gradient, the optimizer steps once after the last bucket (a step that finds an inf must be skipped
+        as a whole, so no bucket may be updated early), unscaling happens inside the Adam kernel."""
         model = self.model
         model.train()
         self.buckets.reset()
-        self._eager, self._adam_begun = step_optimizer, False
+        amp = scaler is not None and scaler.is_enabled()
+        self._eager, self._adam_begun = step_optimizer and not amp, False
         run = self._run = UNetRun(model, images.float().contiguous(), training=True)
         run.timer = self.timer
         run.zero_grads_kept = self._zeroed          # bucket memory: zero since the first step, summed with zeros since
@@ -292,6 +339,8 @@ class DataParallelTrainer:
         else:
             loss = self.criterion(logits, masks)
             (dlogits,) = torch.autograd.grad(loss / self.world, logits)
+        if amp:
+            dlogits = scaler.scale(dlogits)          # d(scale * loss)/dlogits: the scale stays a device scalar
         run.backward(dlogits, grad_alloc=lambda n, shape: self.buckets.views[n], on_ready=self._on_ready)
         run.release()
         self._run = None
@@ -301,7 +350,10 @@ class DataParallelTrainer:
                 w.wait()                     # current stream waits for the collective
         if self._opt_stream is not None:     # and for the bucket-wise optimizer updates behind the collectives
             torch.cuda.current_stream().wait_stream(self._opt_stream)
-        if step_optimizer:
+        if step_optimizer and amp:
+            scaler.step(self.optimizer)          # inf check over the flat gradient, then FlatAdam.step with the scale
+            scaler.update()
+        elif step_optimizer:
             if self._adam_begun:                 # done bucket by bucket beside backward (joined at its end)
                 missing = [b for b in self.buckets.buckets if not b.get("adam")]
                 assert not missing, "a bucket never became ready"

@@ -279,7 +279,10 @@ class UNetRun:
         return False
 
     # ------------------------------------------------------------------ forward
-    def forward(self):
+    def forward(self, count_into=None):
+        """count_into = (masks [B,1,H,W] fp32, counts int64 [4] or [B,4], per_sample, want_logits): the head launch
+        also binarises the logits and adds the confusion counts (evaluation, k_fold.py:289-290); returns None instead
+        of the logits when want_logits is False."""
         m, L = self.m, self.lease
         s = _stream()
         acts = {}
@@ -323,12 +326,22 @@ class UNetRun:
             acts[f"conv_up{k}_1"], acts[f"conv_up{k}_2"] = a1, a2
             cur = a2
         oc = m.out_channels
-        logits = torch.empty(self.B, oc, self.H, self.W, dtype=torch.float32, device=self.device)
         fc = m.final_conv
-        call("uh_head_fwd", self.B, self.H, self.W, 64, oc, cur.ptr, cur.cstride, cur.coff, fc.weight.data_ptr(),
-             fc.bias.data_ptr(), logits.data_ptr(), s)
         self.acts = acts
         self.head_in = cur
+        if count_into is not None:
+            masks, counts, per_sample, want_logits = count_into
+            if oc != 1:
+                raise NotImplementedError("confusion counts inside the head are built for one output channel")
+            logits = (torch.empty(self.B, 1, self.H, self.W, dtype=torch.float32, device=self.device)
+                      if want_logits else None)
+            call("uh_head_fwd_counts", self.B, self.H, self.W, 64, cur.ptr, cur.cstride, cur.coff,
+                 fc.weight.data_ptr(), fc.bias.data_ptr(), _ptr(logits), masks.data_ptr(), int(per_sample),
+                 counts.data_ptr(), s)
+            return logits
+        logits = torch.empty(self.B, oc, self.H, self.W, dtype=torch.float32, device=self.device)
+        call("uh_head_fwd", self.B, self.H, self.W, 64, oc, cur.ptr, cur.cstride, cur.coff, fc.weight.data_ptr(),
+             fc.bias.data_ptr(), logits.data_ptr(), s)
         return logits
 
     # ------------------------------------------------------------------ backward

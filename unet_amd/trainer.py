@@ -308,7 +308,10 @@ def evaluate_model(model, data, device=None, batch_size=8):
             ds = DeviceDataset(images[i:i + chunk], masks[i:i + chunk], dev)
             for j in range(0, len(ds), batch_size):
                 x, m = ds.slice(j, j + batch_size)
-                confusion_counts(model(x), m, counts)
+                if hasattr(model, "predict_counts"):        # the U-Net's head launch binarises and counts as well
+                    model.predict_counts(x, m, counts)
+                else:
+                    confusion_counts(model(x), m, counts)
     tp, tn, fp, fn = counts.cpu().tolist()
     return metrics_from_counts(tp, tn, fp, fn)
 
@@ -337,9 +340,12 @@ def save_results(model, test_data, train_time, filepath, batch_size=1, log=print
     with torch.no_grad():
         for i in range(0, n, batch_size):
             xb, mb = ds.slice(i, i + batch_size)
-            logits = model(xb)
+            if hasattr(model, "predict_counts"):
+                logits = model.predict_counts(xb, mb, counts[i:i + batch_size], per_sample=True, return_logits=True)
+            else:
+                logits = model(xb)
+                confusion_counts(logits, mb, counts[i:i + batch_size], per_sample=True)
             loss_sum += criterion(logits, mb).double()
-            confusion_counts(logits, mb, counts[i:i + batch_size], per_sample=True)
             num_batches += 1
     per = sample_metrics_from_counts(counts.cpu().numpy())
     avg = {k: float(per[k].sum() / n) for k in SAMPLE_KEYS}

@@ -125,6 +125,27 @@ class UNet(nn.Module):
             self._last_run, self.intermediate_features, self._packer = run, feats, pk
         return new
 
+    def predict_counts(self, x, masks, counts, per_sample=False, return_logits=False):
+        """Inference (no gradient) whose head launch also binarises its logits (sigmoid > 0.5) and adds tp, tn, fp, fn
+        against `masks` to `counts` (int64 on the device: [4], or [B,4] with per_sample): what evaluate_model
+        (k_fold.py:281-290) and save_results (test_helper/utils.py:124-131) compute per batch on the host.  Uses the
+        module's current mode (call .eval() first, as those loops do).  Returns the logits if asked for."""
+        if not x.is_cuda:
+            raise RuntimeError("unet_amd.UNet runs on the HIP kernels only: move the model and the input to a "
+                               "ROCm device (there is no CPU path)")
+        B = x.shape[0]
+        masks = masks.float().contiguous()
+        if masks.numel() != B * x.shape[2] * x.shape[3]:
+            raise ValueError(f"masks {tuple(masks.shape)} do not match the {B} one-channel predictions")
+        if counts.dtype != torch.int64 or not counts.is_contiguous() or counts.numel() != (B if per_sample else 1) * 4:
+            raise ValueError("counts must be a contiguous int64 tensor of 4 values per plane")
+        with torch.no_grad():
+            run = UNetRun(self, x.detach().float().contiguous(), training=self.training)
+            logits = run.forward(count_into=(masks, counts, per_sample, return_logits))
+        self.intermediate_features = _Features([run.acts[n] for n in FEATURE_LAYERS], run.lease.pool)
+        run.release()
+        return logits
+
     def forward(self, x):
         if not x.is_cuda:
             raise RuntimeError("unet_amd.UNet runs on the HIP kernels only: move the model and the input to a "
