@@ -18,32 +18,45 @@ __device__ __forceinline__ void split_bf16(float v, bf16& hi, bf16& lo) {
   lo = (bf16)(v - (float)hi);
 }
 
-// x[b][ci][y+ky-1][x+kx-1] for tap k = ci*9 + ky*3 + kx of pixel (b,y,x); 0 outside the image / beyond KK taps
-template <int CIN>
-__device__ __forceinline__ float first_tap(const float* __restrict__ x, int H, int W, long long b, int py, int px, int k,
-                                           bool pixel_ok) {
-  const int ci = (k * 57) >> 9;            // k / 9 for k < 64
-  const int r = k - ci * 9;
-  const int ky = (r * 11) >> 5;            // r / 3 for r < 9
-  const int kx = r - ky * 3;
-  const int yy = py + ky - 1, xx = px + kx - 1;
-  const bool ok = pixel_ok && k < CIN * 9 && yy >= 0 && yy < H && xx >= 0 && xx < W;
-  // The load is unconditional (from element 0 where the tap does not exist): as `ok ? x[i] : 0` it is compiled into a
-  // branch per tap, and the eight taps of a pixel then cost eight memory round trips one after the other.
-  const long long i = ok ? ((b * CIN + ci) * H + yy) * W + xx : 0;
-  const float v = x[i];
-  return ok ? v : 0.f;
-}
+// The taps a lane gathers are the same (ci, ky, kx) for every pixel it visits, so everything about them that does not
+// depend on the pixel is worked out once per kernel: the element offset from the pixel's own position in channel 0 and
+// the row / column displacement for the bounds test (a displacement of 2^20 marks a slot beyond the K taps: it fails
+// every test).  Per pixel and tap that leaves two unsigned compares, two selects and the load.
+template <int CIN, int SLOTS>
+struct FirstTaps {
+  int off[SLOTS], dy[SLOTS], dx[SLOTS];
+  // slot t holds tap k
+  __device__ __forceinline__ void set(int t, int k, int H, int W) {
+    const int ci = (k * 57) >> 9, r = k - ci * 9;        // k / 9 for k < 64
+    const int ky = (r * 11) >> 5, kx = r - ky * 3;       // r / 3 for r < 9
+    const bool real = k < CIN * 9;
+    off[t] = real ? (ci * H + ky - 1) * W + kx - 1 : 0;
+    dy[t] = real ? ky - 1 : (1 << 20);
+    dx[t] = real ? kx - 1 : (1 << 20);
+  }
+  // xb: &x[b][0][py][px] for a pixel inside the image (any valid address otherwise, with inside = false)
+  __device__ __forceinline__ float get(const float* __restrict__ xb, int H, int W, int py, int px, bool inside,
+                                       int t) const {
+    // bitwise &: as && the second compare is compiled into a branch around it
+    const bool ok = inside & ((unsigned)(py + dy[t]) < (unsigned)H) & ((unsigned)(px + dx[t]) < (unsigned)W);
+    const float v = xb[ok ? off[t] : 0];      // unconditional load: a select, not a branch per tap
+    return ok ? v : 0.f;
+  }
+};
 
-template <int CIN>
+// MODE = UH_EPI_RAW_STATS: the conv bias rides in the first free K slot (input 1.0 on interior pixels, weight = bias),
+// so positions outside the image come out of the matrix cores as exact zeros and the epilogue is the statistics and
+// the fp16 store only.  MODE = UH_EPI_AFFINE_RELU: relu(acc * scale + shift), bf16 store.
+template <int CIN, int MODE>
 __global__ __launch_bounds__(256) void conv_first_fwd_kernel(int B, int H, int W, const float* __restrict__ x,
                                                              const float* __restrict__ w,
-                                                             const float* __restrict__ bias, int mode,
+                                                             const float* __restrict__ bias,
                                                              const float* __restrict__ scale,
                                                              const float* __restrict__ shift, char* __restrict__ out,
                                                              int o_cs, int o_co, float* __restrict__ stat_partial) {
   constexpr int KK = CIN * 9;
-  constexpr int NKB = (KK + 31) / 32;
+  constexpr int NKB = (KK + 1 + 31) / 32;          // + 1: the bias slot
+  constexpr bool STATS = MODE == UH_EPI_RAW_STATS;
   __shared__ float red[4][2][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, g = lane >> 4;
@@ -51,33 +64,38 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(int B, int H, int W
   const long long Mp = (long long)B * Hp * Wp;
   const long long nblk = (Mp + 511) / 512;         // a workgroup walks blocks of 512 positions: blockIdx.x, + gridDim.x, ...
 
-  // weight fragments (A operand): tile j, row r = l15 is output channel (r/4)*16 + j*4 + r%4
+  // weight fragments (A operand): tile j, row r = l15 is output channel (j/2)*32 + (r/4)*8 + (j%2)*4 + r%4, so that
+  // the lane of row group g ends up with channels g*8..g*8+7 (tiles 0, 1) and 32+g*8..32+g*8+7 (tiles 2, 3): each of
+  // its two 16-byte stores then lands beside those of the other three groups, 64 contiguous bytes per pixel
   bf16x8 whi[NKB][4], wlo[NKB][4];
 #pragma unroll
   for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int c = (l15 >> 2) * 16 + j * 4 + (l15 & 3);
+      const int c = (j >> 1) * 32 + (l15 >> 2) * 8 + (j & 1) * 4 + (l15 & 3);
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         const int k = kb * 32 + g * 8 + t;
-        const float v = (k < KK) ? w[c * KK + k] : 0.f;
+        float v = (k < KK) ? w[c * KK + k] : 0.f;
+        if (STATS && k == KK && bias) v = bias[c];
         bf16 h, l;
         split_bf16(v, h, l);
         whi[kb][j][t] = h;
         wlo[kb][j][t] = l;
       }
     }
-  // this lane's 16 output channels: g*16 + q
-  float cb[16], csc[16];
+  FirstTaps<CIN, NKB * 8> taps;
 #pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    if (mode == UH_EPI_AFFINE_RELU) {
-      csc[q] = scale[g * 16 + q];
-      cb[q] = shift[g * 16 + q];       // folded inference BN: shift already contains the conv bias
-    } else {
-      csc[q] = 1.f;
-      cb[q] = bias ? bias[g * 16 + q] : 0.f;
+  for (int t = 0; t < NKB * 8; ++t) taps.set(t, (t / 8) * 32 + g * 8 + t % 8, H, W);
+  // the lane's slot that carries the bias (if any): slot index within its NKB * 8
+  const int bias_slot = (STATS && KK / 8 % 4 == g) ? (KK / 32) * 8 + KK % 8 : -1;
+  // this lane's 16 output channels: value q is channel (q/8)*32 + g*8 + q%8
+  float cb[16], csc[16];
+  if (!STATS) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      csc[q] = scale[(q >> 3) * 32 + g * 8 + (q & 7)];
+      cb[q] = shift[(q >> 3) * 32 + g * 8 + (q & 7)];       // folded inference BN: shift already contains the conv bias
     }
   }
   float s1[16], s2[16];
@@ -97,12 +115,14 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(int B, int H, int W
       if (++py == Hp) { py = 0; ++b; }
     }
     const bool interior = (m < Mp && px < W && py < H);
+    const float* xb = interior ? x + ((b * CIN) * H + py) * W + px : x;
     bf16x8 xhi[NKB], xlo[NKB];
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
-        const float v = first_tap<CIN>(x, H, W, b, py, px, kb * 32 + g * 8 + t, interior);
+        float v = taps.get(xb, H, W, py, px, interior, kb * 8 + t);
+        if (STATS && kb * 8 + t == bias_slot) v = interior ? 1.f : 0.f;
         bf16 h, l;
         split_bf16(v, h, l);
         xhi[kb][t] = h;
@@ -119,34 +139,37 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(int B, int H, int W
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[kb][j], xhi[kb], acc, 0, 0, 0);
       }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[j * 4 + e] = acc[e];       // channel g*16 + j*4 + e of pixel l15
+      for (int e = 0; e < 4; ++e) v[j * 4 + e] = acc[e];       // value q = j*4 + e of pixel l15
     }
+    if (STATS) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      float t = v[q];
-      if (mode == UH_EPI_AFFINE_RELU) t = fmaxf(t * csc[q] + cb[q], 0.f);
-      else t += cb[q];
-      t = interior ? t : 0.f;
-      s1[q] += t;
-      s2[q] += t * t;
-      v[q] = t;
+      for (int q = 0; q < 16; ++q) {                           // zero outside the image: every tap was zero
+        s1[q] += v[q];
+        s2[q] += v[q] * v[q];
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float t = fmaxf(v[q] * csc[q] + cb[q], 0.f);
+        v[q] = interior ? t : 0.f;
+      }
     }
     if (m < Mp) {
       float lo8[8], hi8[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) { lo8[q] = v[q]; hi8[q] = v[8 + q]; }
-      char* dst = out + (m * o_cs + o_co + g * 16) * 2;
-      if (mode == UH_EPI_RAW_STATS) {   // BatchNorm input: fp16
+      char* dst = out + (m * o_cs + o_co + g * 8) * 2;
+      if (STATS) {                      // BatchNorm input: fp16
         *(U4*)dst = pack8h(lo8);
-        *(U4*)(dst + 16) = pack8h(hi8);
+        *(U4*)(dst + 64) = pack8h(hi8);
       } else {
         *(U4*)dst = pack8(lo8);
-        *(U4*)(dst + 16) = pack8(hi8);
+        *(U4*)(dst + 64) = pack8(hi8);
       }
     }
   }
   }
-  if (mode == UH_EPI_RAW_STATS) {
+  if (STATS) {
     // sum over the 16 pixels (lanes l15) of every group g, then over the four waves
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
@@ -159,8 +182,8 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(int B, int H, int W
     if (l15 == 0) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        red[wave][0][g * 16 + q] = s1[q];
-        red[wave][1][g * 16 + q] = s2[q];
+        red[wave][0][(q >> 3) * 32 + g * 8 + (q & 7)] = s1[q];
+        red[wave][1][(q >> 3) * 32 + g * 8 + (q & 7)] = s2[q];
       }
     }
     __syncthreads();
@@ -173,10 +196,11 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(int B, int H, int W
 }
 
 // workgroups of the forward launch = rows of its stat_partial: the weight fragments (32 loads and splits per lane) are
-// set up once per workgroup, so a workgroup takes several 512-position blocks
+// set up once per workgroup, so a workgroup takes several 512-position blocks.  The kernel's ~140 registers allow three
+// workgroups per CU: 768 are all resident at once on the 256 CUs (1024 would leave a quarter for a second round).
 extern "C" int uh_conv_first_parts(int B, int H, int W) {
   const long long nblk = (uh_mp(B, H, W) + 511) / 512;
-  return (int)(nblk < 1024 ? nblk : 1024);
+  return (int)(nblk < 768 ? nblk : 768);
 }
 
 extern "C" int uh_conv_first_fwd(int B, int H, int W, int Cin, int Cout, const float* x, const float* w,
@@ -189,11 +213,17 @@ extern "C" int uh_conv_first_fwd(int B, int H, int W, int Cin, int Cout, const f
   UH_REQUIRE(mode != UH_EPI_RAW_STATS || stat_partial, "conv_first_fwd: RAW_STATS needs stat_partial");
   UH_REQUIRE(mode != UH_EPI_AFFINE_RELU || (scale && shift), "conv_first_fwd: AFFINE_RELU needs scale/shift");
   UH_REQUIRE(o_cstride % 8 == 0 && o_coff % 8 == 0 && o_cstride >= o_coff + 64, "conv_first_fwd: bad out view");
+  UH_REQUIRE((long long)Cin * H * W < (1ll << 30), "conv_first_fwd: image of %lld elements exceeds the 32-bit tap offsets",
+             (long long)Cin * H * W);
   const dim3 grid((unsigned)uh_conv_first_parts(B, H, W));
   hipStream_t st = (hipStream_t)s;
-#define LAUNCH(CI)                                                                                                 \
-  hipLaunchKernelGGL((conv_first_fwd_kernel<CI>), grid, dim3(256), 0, st, B, H, W, x, w, bias, mode, scale, shift, \
-                     (char*)out, o_cstride, o_coff, stat_partial)
+#define LAUNCH(CI)                                                                                                  \
+  if (mode == UH_EPI_RAW_STATS)                                                                                     \
+    hipLaunchKernelGGL((conv_first_fwd_kernel<CI, UH_EPI_RAW_STATS>), grid, dim3(256), 0, st, B, H, W, x, w, bias,   \
+                       scale, shift, (char*)out, o_cstride, o_coff, stat_partial);                                  \
+  else                                                                                                              \
+    hipLaunchKernelGGL((conv_first_fwd_kernel<CI, UH_EPI_AFFINE_RELU>), grid, dim3(256), 0, st, B, H, W, x, w, bias, \
+                       scale, shift, (char*)out, o_cstride, o_coff, stat_partial)
   switch (Cin) {
     case 1: LAUNCH(1); break;
     case 2: LAUNCH(2); break;
@@ -225,6 +255,9 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(int B, int H, int
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt) acc[j][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  FirstTaps<CIN, NT> taps;
+#pragma unroll
+  for (int tt = 0; tt < NT; ++tt) taps.set(tt, tt * 16 + l15, H, W);
 
   for (long long pb = (long long)blockIdx.x * 4 + wave; pb < nblk; pb += (long long)gridDim.x * 4) {
     const long long m0 = pb * 32 + g * 8;              // this lane's 8 consecutive positions
@@ -247,9 +280,10 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(int B, int H, int
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       const bool ok = (m0 + t < Mp) && px < W && py < H;
+      const float* xb = ok ? x + ((b * CIN) * H + py) * W + px : x;
 #pragma unroll
       for (int tt = 0; tt < NT; ++tt) {
-        const float v = first_tap<CIN>(x, H, W, b, py, px, tt * 16 + l15, ok);
+        const float v = taps.get(xb, H, W, py, px, ok, tt);
         bf16 h, l;
         split_bf16(v, h, l);
         xhi[tt][t] = h;
@@ -296,6 +330,8 @@ extern "C" int uh_conv_first_wgrad(int B, int H, int W, int Cin, int Cout, const
   UH_REQUIRE(B > 0 && H > 0 && W > 0 && x && dy && partial, "conv_first_wgrad: bad arguments");
   UH_REQUIRE(Cin >= 1 && Cin <= 4, "conv_first_wgrad: Cin=%d must be 1..4", Cin);
   UH_REQUIRE(Cout == 64, "conv_first_wgrad: Cout=%d (only 64 is built)", Cout);
+  UH_REQUIRE((long long)Cin * H * W < (1ll << 30), "conv_first_wgrad: image of %lld elements exceeds the 32-bit tap offsets",
+             (long long)Cin * H * W);
   const dim3 grid((unsigned)uh_conv_first_wgrad_parts(B, H, W));
   hipStream_t st = (hipStream_t)s;
 #define LAUNCH(CI)                                                                                              \
