@@ -83,3 +83,30 @@ def test_cldice_multichannel_and_errors():
         unet_amd.soft_dice_cldice()(t, p)
     with pytest.raises(NotImplementedError):
         unet_amd.soft_dice_cldice()(t.to(DEV)[None], p.to(DEV)[None])
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 7, 5), (1, 64, 58), (2, 33, 59), (1, 41, 117), (3, 100, 76), (2, 256, 256)])
+def test_backward_strip_walk_equals_tile_kernel(B, H, W, monkeypatch):
+    """The backward pass has two kernels for a level: the register strip walk (default; a wave per 58-column strip,
+    R core rows) and the LDS-tile kernel (UNET_AMD_SKEL_TILES=1).  They evaluate the same terms in the same order, so
+    the gradients agree bit for bit: on widths around the strip width, heights that no strip length divides, and
+    tie-heavy inputs (probabilities quantised to 1/8, saturated plateaus), for several strip lengths."""
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    mask = (torch.rand(B, 1, H, W, generator=g) > 0.55).float().to(DEV)
+    probs = torch.rand(B, 1, H, W, generator=g)
+    probs[0] = (probs[0] * 8).round() / 8                    # ties everywhere
+    if B > 1:
+        probs[1, :, : H // 2] = 1.0                          # a saturated plateau
+    probs = probs.clamp(1e-6, 1 - 1e-6).to(DEV).requires_grad_(True)
+    crit = unet_amd.soft_dice_cldice()
+    monkeypatch.setenv("UNET_AMD_SKEL_TILES", "1")
+    (want,) = torch.autograd.grad(crit(mask, probs) * 2.5, probs)
+    monkeypatch.delenv("UNET_AMD_SKEL_TILES")
+    for R in (None, "1", "5", "8", "16", "64"):
+        if R is None:
+            monkeypatch.delenv("UNET_AMD_SKEL_R", raising=False)
+        else:
+            monkeypatch.setenv("UNET_AMD_SKEL_R", R)
+        (got,) = torch.autograd.grad(crit(mask, probs) * 2.5, probs)
+        assert torch.equal(got, want), (R, (got - want).abs().max().item())
+    assert want.abs().max().item() > 0

@@ -15,6 +15,8 @@
 // relu'(0) = 0, clamp passes the gradient on its closed interval.
 // All sums are two-stage (per-workgroup partials, then one finalising workgroup): deterministic, no atomics.
 #include "common.h"
+#include <cstdlib>
+#include <type_traits>
 #pragma clang fp contract(off)   // keep delta - skel*delta as two roundings, like the reference's separate ops
 
 #define SKEL_LEVELS 11            // E_1..E_11, skel_0..skel_10  (num_iter = 10, cl_dice.py:103)
@@ -431,6 +433,215 @@ __global__ __launch_bounds__(256) void skel_bwd_level_kernel(BwdArgs a) {
   }
 }
 
+// ---- backward level k, strip walk --------------------------------------------------------------------------------
+// The same arithmetic as skel_bwd_level_kernel (term for term, in the same order: bit-identical results) without LDS,
+// barriers or index divisions.  A wave owns a strip of 64 columns (58 core columns + 3 halo columns on either side,
+// lane = column) and walks down R core rows; the three stages run as a software pipeline three rows deep in
+// registers: with E_{k+1} row r just arrived, stage A (masks, arg-max of the dilation window) is evaluated for row
+// r-1, stage B (gather of the dilation gradient, routing of the erosion window) for row r-2, stage C (collect at the
+// pixel) for row r-3.  Horizontal neighbours come from the adjacent lanes by DPP wave shifts; every global access is
+// one 256-byte row piece per wave, requested one iteration ahead of its use.
+#define SK_CORE 58
+// wave_shr:1 / wave_shl:1 with bound_ctrl: lanes 0 / 63 receive 0 (their results are halo, never stored)
+__device__ __forceinline__ int from_left(int v) { return __builtin_amdgcn_mov_dpp(v, 0x138, 0xf, 0xf, true); }
+__device__ __forceinline__ int from_right(int v) { return __builtin_amdgcn_mov_dpp(v, 0x130, 0xf, 0xf, true); }
+__device__ __forceinline__ float from_left(float v) {    // the value held by lane - 1 (column x - 1)
+  return __builtin_bit_cast(float, from_left(__builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ float from_right(float v) {   // the value held by lane + 1 (column x + 1)
+  return __builtin_bit_cast(float, from_right(__builtin_bit_cast(int, v)));
+}
+
+template <bool TOP, bool L0>
+__global__ __launch_bounds__(256) void skel_bwd_strip_kernel(BwdArgs a, int planes, int R, int nstrips, int nchunks) {
+  const int lane = threadIdx.x & 63;
+  // the wave's strip: the same for all 64 lanes, and said so (readfirstlane), or the row counter and every row test
+  // below would be vector values with a branch each
+  unsigned item = blockIdx.x * 4u + (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (item >= (unsigned)planes * nstrips * nchunks) return;
+  const int chunk = (int)(item % (unsigned)nchunks);
+  item /= (unsigned)nchunks;
+  const int strip = (int)(item % (unsigned)nstrips);
+  const long long plane = (long long)(item / (unsigned)nstrips) * a.H * a.W;
+  const int H = a.H, W = a.W;
+  const int Y0 = chunk * R, Y1 = (Y0 + R < H) ? Y0 + R : H;
+  const int x = strip * SK_CORE - 3 + lane;
+  const bool inx = x >= 0 && x < W;
+  const bool core = inx && lane >= 3 && lane < 3 + SK_CORE;
+  const long long col = plane + (inx ? x : 0);
+  const float* __restrict__ p_e1 = a.ek1 + col;
+  const float* __restrict__ p_e = a.ek + col;
+  const float* __restrict__ p_sp = L0 ? nullptr : a.skel_prev + col;
+  const float* __restrict__ p_gs = TOP ? a.yt + col : a.gs_in + col;     // top level: dL/dskel comes from y_true
+  const float* __restrict__ p_g1 = TOP ? nullptr : a.ge1_in + col;
+  const float* __restrict__ p_yt = a.yt + col;
+  const float* __restrict__ p_skt = L0 ? a.skt + col : nullptr;
+  const float gout = *a.gout;
+  const float c4 = TOP ? a.coef[4] : 0.f, c5 = TOP ? a.coef[5] : 0.f;
+  const float k1 = L0 ? a.coef[1] : 0.f, k2 = L0 ? a.coef[2] : 0.f, k3 = L0 ? a.coef[3] : 0.f;
+  // row y of a plane, `dflt` outside the image; the load itself is unconditional (from a row inside the image)
+  auto ld = [&](const float* __restrict__ p, int y, float dflt) -> float {
+    const bool ok = (y >= 0) & (y < H);
+    const float v = p[(long long)(ok ? y : 0) * W];
+    return (ok & inx) ? v : dflt;
+  };
+  // the same in two halves, so that a value requested in one iteration is first touched in the next
+  auto ld_raw = [&](const float* __restrict__ p, int y) -> float {
+    const bool ok = (y >= 0) & (y < H);
+    return p[(ok ? y : 0) * W];                        // a plane has fewer than 2^31 pixels (checked on the host)
+  };
+  auto sel = [&](float raw, int y, float dflt) -> float { return ((y >= 0) & (y < H) & inx) ? raw : dflt; };
+  // first maximum of (left, centre, right) of a row of E_{k+1}
+  auto rowmax = [&](float c, float& m, int& arg) {
+    const float l = from_left(c), r = from_right(c);
+    m = l;
+    arg = 0;
+    if (c > m) { m = c; arg = 1; }
+    if (r > m) { m = r; arg = 2; }
+  };
+  // ---- pipeline state.  Three-row windows are rings indexed by the iteration's phase (r - (Y0 - 1)) mod 3: in phase PH
+  // slot PH holds the oldest row, PH+1 the middle one, PH+2 (mod 3) receives the new one; the loop body is written
+  // once as a lambda over the phase and instantiated three times, so the windows rotate by renaming, without moves.
+  float mx[3];                       // row maxima of E_{k+1}: rows r-2, r-1, r
+  int ax[3];
+  float gdl[3], gdc[3], gdr[3];      // stage A rows r-3, r-2, r-1: dL/dD and the arg-max slot, with both neighbours
+  int aml[3], amc[3], amr[3];
+  float ec[3];                       // E_k rows r-3, r-2, r-1 (clamped at level 0; +inf outside the image)
+  float rawc[3];                     // level 0: the same rows as given (the clamp's pass-through test)
+  float gvc[3], ghc[3];              // stage B rows r-4, r-3, r-2
+  int cdc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    gdl[i] = gdc[i] = gdr[i] = 0.f;
+    aml[i] = amc[i] = amr[i] = -1;
+    ec[i] = INFINITY;
+    rawc[i] = 0.f;
+    gvc[i] = ghc[i] = 0.f;
+    cdc[i] = 15;
+  }
+  rowmax(ld(p_e1, Y0 - 3, -INFINITY), mx[1], ax[1]);      // phase 0: slots 1, 2 hold rows r-2, r-1; slot 0 takes row r
+  rowmax(ld(p_e1, Y0 - 2, -INFINITY), mx[2], ax[2]);
+  // operands of the first iteration (r = Y0 - 1): E_{k+1} row r, and row r-1 of E_k, dL/dskel, skel_{k-1}
+  float q_e1 = ld_raw(p_e1, Y0 - 1);
+  float q_e = ld_raw(p_e, Y0 - 2);
+  float q_gs = ld_raw(p_gs, Y0 - 2);
+  float q_sp = L0 ? 0.f : ld_raw(p_sp, Y0 - 2);
+  float q_g1 = 0.f, q_yt = 0.f, q_skt = 0.f;
+
+  auto body = [&](auto phase, int r) {
+    constexpr int PH = decltype(phase)::value;
+    constexpr int O = PH % 3, M = (PH + 1) % 3, N = (PH + 2) % 3;     // oldest, middle, newest slot of the A / E rings
+    // requests for the next iteration
+    const float n_e1 = ld_raw(p_e1, r + 1);
+    const float n_e = ld_raw(p_e, r);
+    const float n_gs = ld_raw(p_gs, r);
+    const float n_sp = L0 ? 0.f : ld_raw(p_sp, r);
+    const float n_g1 = TOP ? 0.f : ld_raw(p_g1, r - 1);
+    const float n_yt = L0 ? ld_raw(p_yt, r - 2) : 0.f;
+    const float n_skt = L0 ? ld_raw(p_skt, r - 2) : 0.f;
+    // this iteration's operands: what the previous one requested
+    const float c_e1 = sel(q_e1, r, -INFINITY);
+    const float c_e = sel(q_e, r - 1, INFINITY);
+    const float c_gs = sel(q_gs, r - 1, 0.f);
+    const float c_sp = sel(q_sp, r - 1, 0.f);
+    const float c_g1 = (TOP || r == Y0 - 1) ? 0.f : sel(q_g1, r - 2, 0.f);
+    const float c_yt = sel(q_yt, r - 3, 0.f);
+    const float c_skt = sel(q_skt, r - 3, 0.f);
+
+    // ---- stage A, row r-1: the row maxima ring holds rows r-2, r-1 in slots M, N and takes row r in slot O
+    rowmax(c_e1, mx[O], ax[O]);
+    {
+      const int y = r - 1;
+      const bool in = inx & (y >= 0) & (y < H);
+      float best = mx[M];
+      int am = ax[M];
+      if (mx[N] > best) { best = mx[N]; am = 3 + ax[N]; }
+      if (mx[O] > best) { best = mx[O]; am = 6 + ax[O]; }
+      const float e = L0 ? clamp01(c_e) : c_e;
+      const float diff = e - best;
+      const float delta = fmaxf(diff, 0.f);
+      const float gs = TOP ? gout * (c4 * clamp01(c_gs) + c5) : c_gs;
+      float gdelta = gs;
+      if (!L0) {
+        const float sp = c_sp;
+        const float prod = sp * delta;
+        const bool on = (delta - prod) > 0.f;
+        gdelta = on ? gs * (1.f - sp) : 0.f;
+        if (core & in & (y >= Y0) & (y < Y1)) a.gs_out[plane + (long long)y * W + x] = on ? gs * (1.f - delta) : gs;
+      }
+      const float dmask = diff > 0.f ? gdelta : 0.f;
+      const float gd = in ? -dmask : 0.f;
+      const int amv = in ? am : -1;
+      // the new row replaces the oldest one: afterwards slots M, N, O hold rows r-3, r-2, r-1
+      gdc[O] = gd; gdl[O] = from_left(gd); gdr[O] = from_right(gd);
+      amc[O] = amv; aml[O] = from_left(amv); amr[O] = from_right(amv);
+      ec[O] = in ? e : INFINITY;
+      if (L0) rawc[O] = c_e;
+    }
+    // ---- stage B, row r-2 (first needed: row Y0 - 1); stage-A rows r-3, r-2, r-1 are in slots M, N, O
+    if (r > Y0) {
+      const int y = r - 2;
+      const bool in = inx & (y >= 0) & (y < H);
+      float v = c_g1;
+      v += (aml[M] == 8) ? gdl[M] : 0.f;
+      v += (amc[M] == 7) ? gdc[M] : 0.f;
+      v += (amr[M] == 6) ? gdr[M] : 0.f;
+      v += (aml[N] == 5) ? gdl[N] : 0.f;
+      v += (amc[N] == 4) ? gdc[N] : 0.f;
+      v += (amr[N] == 3) ? gdr[N] : 0.f;
+      v += (aml[O] == 2) ? gdl[O] : 0.f;
+      v += (amc[O] == 1) ? gdc[O] : 0.f;
+      v += (amr[O] == 0) ? gdr[O] : 0.f;
+      const float c = ec[N];
+      const float el = from_left(c), er = from_right(c);
+      float vmin = ec[M];
+      int varg = -1;
+      if (c < vmin) { vmin = c; varg = 0; }
+      if (ec[O] < vmin) { vmin = ec[O]; varg = 1; }
+      float hmin = el;
+      int harg = -1;
+      if (c < hmin) { hmin = c; harg = 0; }
+      if (er < hmin) { hmin = er; harg = 1; }
+      const float wv = vmin < hmin ? 1.f : (vmin == hmin ? 0.5f : 0.f);
+      // stage-B ring: the new row (r-2) replaces the oldest in slot O; rows r-4, r-3 stay in slots M, N
+      gvc[O] = in ? v * wv : 0.f;
+      ghc[O] = in ? v * (1.f - wv) : 0.f;
+      cdc[O] = in ? ((varg + 1) | ((harg + 1) << 2)) : 15;
+    }
+    // ---- stage C, row r-3: stage-B rows r-4, r-3, r-2 are in slots M, N, O; the direct term dmask of row r-3 is
+    // minus the stage-A value in slot M
+    if (r >= Y0 + 3) {
+      const int y = r - 3;
+      const float ghl = from_left(ghc[N]), ghr = from_right(ghc[N]);
+      const int cdl = from_left(cdc[N]), cdr = from_right(cdc[N]);
+      float acc = -gdc[M];
+      int c = cdc[N];
+      if ((c & 3) == 1) acc += gvc[N];
+      if ((c >> 2) == 1) acc += ghc[N];
+      c = cdc[M];                                            // window above: p is its bottom row
+      if (c != 15 && (c & 3) == 2) acc += gvc[M];
+      c = cdc[O];                                            // window below: p is its top row
+      if (c != 15 && (c & 3) == 0) acc += gvc[O];
+      if (cdl != 15 && (cdl >> 2) == 2) acc += ghl;          // window to the left: p is its right column
+      if (cdr != 15 && (cdr >> 2) == 0) acc += ghr;          // window to the right: p is its left column
+      if (L0) {
+        const float raw = rawc[M];
+        const float t = clamp01(c_yt);
+        const float direct = gout * (k1 * t + k2 + k3 * c_skt);
+        acc = (raw >= 0.f && raw <= 1.f) ? acc + direct : 0.f;
+      }
+      if (core) a.ge_out[plane + (long long)y * W + x] = acc;        // Y0 <= y < Y1 by the loop bounds
+    }
+    q_e1 = n_e1; q_e = n_e; q_gs = n_gs; q_sp = n_sp; q_g1 = n_g1; q_yt = n_yt; q_skt = n_skt;
+  };
+  const int last = Y1 + 2;
+  for (int r = Y0 - 1; r <= last; r += 3) {
+    body(std::integral_constant<int, 0>{}, r);
+    if (r + 1 <= last) body(std::integral_constant<int, 1>{}, r + 1);
+    if (r + 2 <= last) body(std::integral_constant<int, 2>{}, r + 2);
+  }
+}
+
 // ---- host entry points ----------------------------------------------------------------------------------------
 static int grid_for(long long n) {
   long long b = (n + 255) / 256;
@@ -544,6 +755,25 @@ extern "C" int uh_cldice_backward(int planes, int H, int W, const float* y_true,
   float* gs[2] = {scratch, scratch + n};
   float* ge[2] = {scratch + 2 * n, scratch + 3 * n};
   const dim3 grid(uh_cdiv(W, BT), uh_cdiv(H, BT), planes);
+  // UNET_AMD_SKEL_TILES=1: the LDS-tile kernel (one workgroup per 32x32 tile) instead of the strip walk; both give the
+  // same bits.  UNET_AMD_SKEL_R: core rows per strip-walk wave.
+  const char* env = getenv("UNET_AMD_SKEL_TILES");
+  const bool tiles = env && atoi(env) != 0;
+  const int nstrips = uh_cdiv(W, SK_CORE);
+  int R = 0;
+  if (const char* e = getenv("UNET_AMD_SKEL_R")) R = atoi(e);
+  if (R <= 0) {
+    // A wave walks R + 4 rows, so longer strips waste less; but a wave's rows follow one another through ~250 dependent
+    // instructions each, and it takes about five waves per SIMD (5120 on the chip) to keep the ALUs issuing.  Measured
+    // per loss call at 32 x 256 x 256: R = 8 (5120 waves) 385-392 us, 16 (2560) 421-426, 32 (1280) 487, 64 (640) 635;
+    // at 4 x 1024 x 1024: R = 8 750 us, 16 727, 32 878.
+    R = ((long long)planes * nstrips * uh_cdiv(H, 16) >= 5120) ? 16 : 8;
+  }
+  const int nchunks = uh_cdiv(H, R);
+  const long long items = (long long)planes * nstrips * nchunks;
+  UH_REQUIRE(items < (1ll << 32) && (long long)H * W < (1ll << 31), "cldice_backward: %lld strips of a %d x %d plane",
+             items, H, W);
+  const dim3 sgrid((unsigned)((items + 3) / 4));
   for (int k = SKEL_LEVELS - 1; k >= 0; --k) {
     BwdArgs a;
     a.ek = (k == 0) ? y_pred : E + (long long)(k - 1) * n;
@@ -561,7 +791,14 @@ extern "C" int uh_cldice_backward(int planes, int H, int W, const float* y_true,
     a.gout = grad_out;
     a.H = H;
     a.W = W;
-    hipLaunchKernelGGL(skel_bwd_level_kernel, grid, dim3(256), 0, st, a);
+    if (tiles)
+      hipLaunchKernelGGL(skel_bwd_level_kernel, grid, dim3(256), 0, st, a);
+    else if (a.top)
+      hipLaunchKernelGGL((skel_bwd_strip_kernel<true, false>), sgrid, dim3(256), 0, st, a, planes, R, nstrips, nchunks);
+    else if (a.level0)
+      hipLaunchKernelGGL((skel_bwd_strip_kernel<false, true>), sgrid, dim3(256), 0, st, a, planes, R, nstrips, nchunks);
+    else
+      hipLaunchKernelGGL((skel_bwd_strip_kernel<false, false>), sgrid, dim3(256), 0, st, a, planes, R, nstrips, nchunks);
   }
   return uh_check_launch("cldice_backward");
 }
