@@ -457,7 +457,12 @@ __global__ __launch_bounds__(256) void skel_bwd_strip_kernel(BwdArgs a, int plan
   const int lane = threadIdx.x & 63;
   // the wave's strip: the same for all 64 lanes, and said so (readfirstlane), or the row counter and every row test
   // below would be vector values with a branch each
-  unsigned item = blockIdx.x * 4u + (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  // Workgroups are handed to the eight XCDs in turn, and each XCD has its own L2: workgroup b works on the b/8-th block
+  // of four strips of XCD b%8's contiguous share, so that strips whose halo rows overlap meet in one L2.
+  // (The grid is a multiple of eight workgroups.)
+  const unsigned per_xcd = gridDim.x >> 3;
+  const unsigned lblk = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  unsigned item = lblk * 4u + (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (item >= (unsigned)planes * nstrips * nchunks) return;
   const int chunk = (int)(item % (unsigned)nchunks);
   item /= (unsigned)nchunks;
@@ -773,7 +778,7 @@ extern "C" int uh_cldice_backward(int planes, int H, int W, const float* y_true,
   const long long items = (long long)planes * nstrips * nchunks;
   UH_REQUIRE(items < (1ll << 32) && (long long)H * W < (1ll << 31), "cldice_backward: %lld strips of a %d x %d plane",
              items, H, W);
-  const dim3 sgrid((unsigned)((items + 3) / 4));
+  const dim3 sgrid((unsigned)(((items + 3) / 4 + 7) / 8 * 8));     // four strips per workgroup, eight workgroups a round
   for (int k = SKEL_LEVELS - 1; k >= 0; --k) {
     BwdArgs a;
     a.ek = (k == 0) ? y_pred : E + (long long)(k - 1) * n;
