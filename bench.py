@@ -79,7 +79,8 @@ def cpu_baseline(threads):
             "sample": "4 images 3x256x256 per step (batch 4, 1/8 of the GPU batch), fp32, 1 warm-up + 3 timed steps, median"}
 
 
-TRAFFIC_FILE = "r02_traffic.json"   # PMC passes of the kernels in this tree (tools/prof_round.sh writes it)
+TRAFFIC_FILE = "r03_traffic.json"   # PMC passes of the kernels in this tree (tools/prof_round.sh writes it)
+CLDICE_TRAFFIC_FILE = "r03_cldice_traffic.json"   # the same for the clDice loss alone (tools/prof_cldice.sh)
 PEAK_HBM = 8.0e12             # MI355X HBM3E, B/s
 CLDICE_BYTES_PER_PIXEL = 592   # both skeletons forward + the prediction's backward + the reductions, fp32, each plane once per pass
 
@@ -93,18 +94,16 @@ def lunext_result(args, with_cpu_baseline):
     torch.cuda.set_device(dev)
     torch.manual_seed(0)
     model = unet_amd.LUNeXt(3, 1).to(dev).train()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
+    from unet_amd.dp import LUNeXtTrainer
+    # the loop body of training_utils.py:131-170 with model_type "LUNeXt", custom_loss "cl_dice":
+    # probs = sigmoid(model(x)).clamp(1e-6, 1 - 1e-6); loss = soft_dice_cldice()(m, probs); backward; Adam
+    trainer = LUNeXtTrainer(model, lr=1e-3, criterion="cl_dice", standalone=True)
     crit = unet_amd.soft_dice_cldice()
     x, m = synth_batch(args.batch, 3, args.size, args.size)
     x, m = x.to(dev), m.to(dev)
 
     def step():
-        opt.zero_grad(set_to_none=True)
-        probs = torch.sigmoid(model(x)).clamp(1e-6, 1 - 1e-6)         # training_utils.py:146
-        loss = crit(m, probs)
-        loss.backward()
-        opt.step()
-        return loss
+        return trainer.train_step(x, m)
 
     for _ in range(args.warmup):
         step()
@@ -128,6 +127,13 @@ def lunext_result(args, with_cpu_baseline):
     t_loss = e0.elapsed_time(e1) * 1e-3 / reps
     pixels = args.batch * args.size * args.size
     achieved = CLDICE_BYTES_PER_PIXEL * pixels / t_loss
+    # L2 memory-side bytes of one loss call, from the committed PMC passes of these kernels (a profiler cannot run
+    # inside this process); only valid for the default workload size
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", CLDICE_TRAFFIC_FILE)
+    if os.path.exists(tpath) and args.size == IMG and args.batch == BATCH_PER_GPU:
+        with open(tpath) as fh:
+            traffic = json.load(fh)["loss_kernels_traffic_bytes_per_call"]
     out = {"metric": "train imgs/sec, LUNeXt 256^2 + clDice soft-skeleton loss, 1 MI355X", "value": round(args.batch * args.steps / dt, 2),
            "unit": "img/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
@@ -136,7 +142,9 @@ def lunext_result(args, with_cpu_baseline):
                                   "(BASELINE configs[2])", "loss_last_step": round(loss.item(), 6)},
            "roofline": {"bound": "hbm", "kernel": "clDice loss (soft-skeleton forward of both inputs + backward)",
                         "achieved": round(achieved / 1e9, 1), "peak": PEAK_HBM / 1e9, "unit": "GB/s",
-                        "frac": round(achieved / PEAK_HBM, 4), "traffic": None,
+                        "frac": round(achieved / PEAK_HBM, 4), "traffic": traffic,
+                        "traffic_unit": "bytes per loss call (L2 memory-side reads + writes, Infinity-Cache hits included: "
+                                        "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/" + CLDICE_TRAFFIC_FILE + ")",
                         "ms_per_call": round(t_loss * 1e3, 3), "bytes_per_pixel": CLDICE_BYTES_PER_PIXEL}}
     if with_cpu_baseline:
         from oracle import ref_cpu

@@ -223,6 +223,10 @@ int uh_depth_to_space2(int B, int H, int W, int C, const void* in, int i_cstride
 int uh_colsum_parts(long long Mp, int C);
 int uh_colsum(long long Mp, int C, const void* x, int cstride, int coff, float* partial, uh_stream s);
 int uh_colsum_finalize(const float* partial, int P, int C, int fold, float* out, int accumulate, uh_stream s);
+/* out[i] = sum_p partial[p][cols[i]], i < n_out (cols: n_out ints on the device, each in [0, C)): the sums of one pass
+ * written straight into the layout of the parameter gradients they are (autograd's accumulation of lunext.py's padded
+ * 3-channel level and of several biases summed in one pass), no copies behind it */
+int uh_colsum_finalize_gather(const float* partial, int P, int C, int n_out, const int* cols, float* out, uh_stream s);
 
 /* ---- 1x1 segmentation head Conv2d(C -> OC) (unet.py:173; lunext.py:257), fp32 NCHW logits ------ */
 int uh_head_fwd(int B, int H, int W, int C, int OC, const void* a, int a_cstride, int a_coff,
@@ -335,6 +339,13 @@ int uh_adam_step(long long n, float* p, const float* g, float* m, float* v, floa
 int uh_adam_step_amp(long long n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2,
                      float eps, float weight_decay, int step, const float* grad_scale, const float* found_inf,
                      const float* step_dev, uh_stream s);
+
+/* ---- probs = sigmoid(outputs).clamp(lo, hi), the glue in front of the clDice loss (trainer/training_utils.py:146,162,
+ * 201), and its backward: dlogits = dprobs * s (1 - s) where lo <= s <= hi (s = the unclamped sigmoid), else 0.
+ * fp32, n elements, 16-byte aligned buffers. */
+int uh_sigmoid_clamp(long long n, const float* logits, float lo, float hi, float* probs, uh_stream s);
+int uh_sigmoid_clamp_bwd(long long n, const float* logits, float lo, float hi, const float* dprobs, float* dlogits,
+                         uh_stream s);
 
 /* ---- nn.BCEWithLogitsLoss() as the trainer builds it (trainer/training_utils.py:105: mean reduction, no weights),
  * forward and backward in one pass over fp32 logits and targets of n elements:

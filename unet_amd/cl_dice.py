@@ -59,6 +59,32 @@ class _ClDiceFn(torch.autograd.Function):
         return None, grad, None, None
 
 
+def cldice_with_logits(y_true, logits, alpha=0.5, smooth=1.0, lo=1e-6, hi=1 - 1e-6, grad_scale=1.0):
+    """The trainer's clDice branch (training_utils.py:146-148) without autograd:
+        probs = sigmoid(logits).clamp(lo, hi); loss = soft_dice_cldice(alpha, smooth)(y_true, probs)
+    returns (loss, grad_scale * d loss / d logits), both from the HIP kernels: one launch for sigmoid + clamp and one for
+    their backward instead of six element-wise launches around the loss."""
+    planes, H, W = _planes(logits, "logits")
+    if y_true.shape != logits.shape:
+        raise ValueError(f"y_true {tuple(y_true.shape)} and logits {tuple(logits.shape)} differ")
+    yt = y_true.detach().float().contiguous()
+    x = logits.detach().float().contiguous()
+    dev, s, n = x.device, _stream(), x.numel()
+    probs = torch.empty_like(x)
+    call("uh_sigmoid_clamp", n, x.data_ptr(), float(lo), float(hi), probs.data_ptr(), s)
+    ws = torch.empty(lib.uh_cldice_workspace(planes, H, W) // 4, dtype=torch.float32, device=dev)
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    call("uh_cldice_forward", planes, H, W, yt.data_ptr(), probs.data_ptr(), float(alpha), float(smooth),
+         ws.data_ptr(), loss.data_ptr(), s)
+    seed = torch.full((), float(grad_scale), dtype=torch.float32, device=dev)
+    dprobs = torch.empty_like(x)
+    call("uh_cldice_backward", planes, H, W, yt.data_ptr(), probs.data_ptr(), ws.data_ptr(), seed.data_ptr(),
+         dprobs.data_ptr(), s)
+    dlogits = probs                                           # the probabilities are not needed any more
+    call("uh_sigmoid_clamp_bwd", n, x.data_ptr(), float(lo), float(hi), dprobs.data_ptr(), dlogits.data_ptr(), s)
+    return loss, dlogits
+
+
 class SoftSkeletonize(nn.Module):
     """cl_dice.py:5-50.  The HIP kernel is built for num_iter = 10, the only value the reference instantiates
     (cl_dice.py:57,103); forward only (the differentiable path is soft_dice_cldice / soft_cldice)."""

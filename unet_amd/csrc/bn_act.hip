@@ -341,6 +341,36 @@ extern "C" int uh_colsum_finalize(const float* partial, int P, int C, int fold, 
   return uh_check_launch("colsum_finalize");
 }
 
+// out[i] = sum_p partial[p][cols[i]] for i < n_out: a finalisation that lays its sums out as the caller's gradient
+// tensors lie in memory (e.g. an [8][8]-padded 1x1 weight gradient into a [3][3] parameter, several bias gradients of
+// one column-sum pass into their separate places) without copy launches behind it.  cols: device array of n_out ints.
+__global__ __launch_bounds__(256) void colsum_finalize_gather_kernel(const float* __restrict__ partial, int P, int C,
+                                                                     int n_out, const int* __restrict__ cols,
+                                                                     float* __restrict__ out) {
+  __shared__ double lds[256];
+  const int i = blockIdx.x * 8 + (threadIdx.x & 7), slot = threadIdx.x >> 3;     // 32 row slots per output
+  double s = 0.0;
+  if (i < n_out) {
+    const int c = cols[i];
+    for (int p = slot; p < P; p += 32) s += (double)partial[(long long)p * C + c];
+  }
+  lds[threadIdx.x] = s;
+  __syncthreads();
+  for (int stride = 16; stride > 0; stride >>= 1) {
+    if (slot < stride) lds[threadIdx.x] += lds[threadIdx.x + stride * 8];
+    __syncthreads();
+  }
+  if (threadIdx.x < 8 && i < n_out) out[i] = (float)lds[threadIdx.x];
+}
+
+extern "C" int uh_colsum_finalize_gather(const float* partial, int P, int C, int n_out, const int* cols, float* out,
+                                         uh_stream s) {
+  UH_REQUIRE(partial && cols && out && P > 0 && C > 0 && n_out > 0, "colsum_finalize_gather: bad arguments");
+  hipLaunchKernelGGL(colsum_finalize_gather_kernel, dim3((n_out + 7) / 8), dim3(256), 0, (hipStream_t)s, partial, P, C,
+                     n_out, cols, out);
+  return uh_check_launch("colsum_finalize_gather");
+}
+
 // ---- MaxPool2d(2,2) -----------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(int B, int H, int W, int C, const char* __restrict__ a,
                                                            int a_cs, int a_co, char* __restrict__ out, int o_cs,

@@ -106,6 +106,42 @@ class GradBuckets:
             b.pop("adam", None)
 
 
+class FlatGrads:
+    """All parameter gradients of a model in ONE flat fp32 buffer, in a given order of parameter names: `views[name]`
+    is the gradient tensor of a parameter (also installed as its .grad), `span(name, n)` the n floats that start where
+    that parameter's gradient starts.  What FlatAdam needs of GradBuckets (`flat`, `order`), without the buckets."""
+
+    def __init__(self, model, order=None, aligned=None):
+        """aligned(name) -> True for parameters that must start on a 16-byte boundary (kernels that read them with
+        vector loads): up to three floats of padding go in front of those; all others follow their predecessor
+        directly."""
+        params = dict(model.named_parameters())
+        order = list(order) if order is not None else list(params)
+        assert sorted(order) == sorted(params), "order must name every parameter once"
+        dev = next(model.parameters()).device
+        self.order = order
+        self.offset = {}
+        off = 0
+        for n in order:
+            if aligned is not None and aligned(n):
+                off = (off + 3) // 4 * 4
+            self.offset[n] = off
+            off += params[n].numel()
+        self.total = off
+        self.flat = torch.zeros((self.total + 3) // 4 * 4, dtype=torch.float32, device=dev)
+        self.views = {}
+        for n in order:
+            p = params[n]
+            self.views[n] = self.flat[self.offset[n]:self.offset[n] + p.numel()].view(p.shape)
+            p.grad = self.views[n]
+
+    def span(self, name, n):
+        off = self.offset[name]
+        if off + n > self.total:
+            raise ValueError(f"{n} floats from {name} run past the end of the gradient buffer")
+        return self.flat[off:off + n]
+
+
 class FlatAdam:
     """torch.optim.Adam(model.parameters(), lr) (training_utils.py:107) as one kernel launch: the parameters are
     re-pointed into one flat fp32 buffer laid out like the gradient buckets, so p, g, m, v are four flat arrays.
@@ -127,10 +163,13 @@ class FlatAdam:
         self.steps = 0
         self._steps_dev = None             # device-side count of the steps actually taken (AMP: skipped ones excluded)
         params = dict(model.named_parameters())
+        offsets = getattr(buckets, "offset", None)     # FlatGrads may pad in front of some parameters
         off = 0
         with torch.no_grad():
             for n in buckets.order:
                 q = params[n]
+                if offsets is not None:
+                    off = offsets[n]
                 view = self.p[off:off + q.numel()].view(q.shape)
                 view.copy_(q.data)
                 q.data = view                      # the module's parameter now lives in the flat buffer
@@ -417,3 +456,58 @@ class GradAverager:
             have = [(p, v) for p, v in views if p.grad is not None]
             if have:
                 torch._foreach_copy_([p.grad for p, _ in have], [v for _, v in have])
+
+
+class LUNeXtTrainer:
+    """fwd + loss + bwd + Adam for LUNeXt (the loop body of trainer/training_utils.py:131-170 with model_type
+    "LUNeXt") without autograd in the way: the backward pass writes every parameter gradient into one flat buffer
+    (FlatGrads), the optimizer is one uh_adam_step launch over it (FlatAdam) instead of torch's multi-tensor sweeps,
+    and with custom_loss "cl_dice" the glue around the loss (sigmoid, clamp and their backward) is two launches
+    (cl_dice.cldice_with_logits).  Inside an initialised process group (unless standalone) the flat gradient is
+    all-reduced once per step (14 MB: one collective) and 1/world is folded into the loss gradient.
+
+    criterion: "cl_dice", "bce" or a callable (logits, masks) -> loss, differentiated by autograd at the logits."""
+
+    def __init__(self, model, lr=1e-3, criterion="bce", process_group=None, standalone=False):
+        from .lunext import flat_param_order
+        self.model = model
+        joined = dist.is_initialized() and not standalone
+        self.world = dist.get_world_size(process_group) if joined else 1
+        self.rank = dist.get_rank(process_group) if joined else 0
+        self.group = process_group
+        self.criterion = criterion
+        if joined and self.world > 1:
+            for t in list(model.parameters()) + list(model.buffers()):
+                dist.broadcast(t.data, src=0, group=process_group)
+        # the depthwise kernels read their [C][3][3] filters with 16-byte loads
+        self.grads = FlatGrads(model, flat_param_order(model), aligned=lambda n: n.endswith("depthwise.weight"))
+        self.optimizer = FlatAdam(model, self.grads, lr=lr)
+
+    def _loss(self, logits, masks):
+        scale = 1.0 / self.world
+        c = self.criterion
+        if c == "cl_dice":
+            from .cl_dice import cldice_with_logits
+            return cldice_with_logits(masks, logits, grad_scale=scale)
+        if c == "bce" and masks.shape == logits.shape:
+            return bce_with_logits(logits, masks, scale)
+        fn = nn.BCEWithLogitsLoss() if c == "bce" else c
+        lg = logits.detach().requires_grad_(True)
+        loss = fn(lg, masks)
+        (dlogits,) = torch.autograd.grad(loss * scale, lg)
+        return loss.detach(), dlogits
+
+    def train_step(self, images, masks):
+        """images [b,C,H,W], masks [b,1,H,W] on the model's device.  Returns the local loss (0-dim tensor)."""
+        from .lunext import LUNeXtRun
+        model = self.model
+        model.train()
+        run = LUNeXtRun(model, images.float().contiguous(), training=True)
+        logits = run.forward()
+        loss, dlogits = self._loss(logits, masks)
+        run.backward(dlogits, gflat=self.grads)
+        run.release()
+        if self.world > 1:
+            dist.all_reduce(self.grads.flat, op=dist.ReduceOp.SUM, group=self.group)
+        self.optimizer.step()
+        return loss.detach()

@@ -82,6 +82,23 @@ class LUNeXtRun:
         self._side_used = None
         self.packer = lunext_packer_for(module, x.device)       # bf16 GEMM operands, one repack launch per direction
         self.wf = None
+        # set by a caller that keeps all parameter gradients in one flat buffer (dp.FlatGrads, laid out by
+        # flat_param_order below): every gradient is then written where it lives, by the kernel that makes it
+        self.gflat = None
+
+    def _gnew(self, name, shape):
+        """the gradient tensor of parameter `name`: the caller's view of its flat buffer, or a new tensor"""
+        if self.gflat is not None:
+            return self.gflat.views[name]
+        return torch.empty(shape, dtype=torch.float32, device=self.device)
+
+    def _table(self, key, build):
+        """a small int32 index table on the device, built once per module (uh_colsum_finalize_gather's `cols`)"""
+        tabs = self.m.__dict__.setdefault("_gather_tables", {})
+        t = tabs.get(key)
+        if t is None or t.device != self.device:
+            t = tabs[key] = torch.tensor(build(), dtype=torch.int32, device=self.device)
+        return t
 
     # ------------------------------------------------------------------ depthwise block
     @ranged(lambda name, *a: "fwd/" + name)
@@ -137,22 +154,25 @@ class LUNeXtRun:
         call("uh_bn_res_relu_bwd_reduce", x.Mp, Cp, da.ptr, da.cstride, da.coff, y.ptr, y.cstride, y.coff, x.ptr,
              x.cstride, x.coff, *st, partial.data_ptr(), s)
         coef = Ls.f32(2 * Cp)
-        dgb = torch.empty(2, C, dtype=torch.float32, device=self.device)     # the kernel writes the gradient tensors
-        call("uh_bn_bwd_finalize", partial.data_ptr(), parts, Cp, C, B * H * W, dgb[0].data_ptr(), dgb[1].data_ptr(),
-             coef.data_ptr(), 0, s)
-        grads[name + ".bn.weight"], grads[name + ".bn.bias"] = dgb[0], dgb[1]
+        if self.gflat is not None:
+            dgam, dbet = self.gflat.views[name + ".bn.weight"], self.gflat.views[name + ".bn.bias"]
+        else:
+            dgam, dbet = torch.empty(2, C, dtype=torch.float32, device=self.device).unbind(0)
+        call("uh_bn_bwd_finalize", partial.data_ptr(), parts, Cp, C, B * H * W, dgam.data_ptr(), dbet.data_ptr(),
+             coef.data_ptr(), 0, s)                                          # the kernel writes the gradient tensors
+        grads[name + ".bn.weight"], grads[name + ".bn.bias"] = dgam, dbet
         if FUSED_DW_BWD:
             wparts = L.uh_dwblock_bwd_parts(B, H, W, Cp)
             wp = Ls.f32(wparts * 9 * Cp)
             dx = Ls.act(B, H, W, Cp)
-            dw = torch.empty(C, 1, 3, 3, dtype=torch.float32, device=self.device)
+            dw = self._gnew(name + ".depthwise.weight", (C, 1, 3, 3))
             call("uh_dwblock_bwd", B, H, W, Cp, da.ptr, da.cstride, da.coff, y.ptr, y.cstride, y.coff, x.ptr,
                  x.cstride, x.coff, rec.wt.data_ptr(), C, *st, coef.data_ptr(), dx.ptr, dx.cstride,
                  dx.coff, wp.data_ptr(), s)
             with self._side() as s2:
                 call("uh_dw_wgrad_finalize", wp.data_ptr(), wparts, Cp, C, dw.data_ptr(), s2)
             grads[name + ".depthwise.weight"] = dw
-            grads[name + ".depthwise.bias"] = self._zeros(C)
+            grads[name + ".depthwise.bias"] = self._gzero(name + ".depthwise.bias", C)
             return dx
         dy, dr = Ls.act(B, H, W, Cp), Ls.act(B, H, W, Cp)
         call("uh_bn_res_relu_bwd_apply", x.Mp, Cp, da.ptr, da.cstride, da.coff, y.ptr, y.cstride, y.coff, x.ptr,
@@ -160,13 +180,13 @@ class LUNeXtRun:
              dr.coff, s)
         wparts = L.uh_dw_parts(B, H, W, Cp)
         wp = Ls.f32(wparts * 9 * Cp)
-        dw = torch.empty(C, 1, 3, 3, dtype=torch.float32, device=self.device)
+        dw = self._gnew(name + ".depthwise.weight", (C, 1, 3, 3))
         with self._side() as s2:                     # beside the input gradient below: both only read dy and x
             call("uh_dwconv3x3_wgrad", B, H, W, Cp, dy.ptr, dy.cstride, dy.coff, x.ptr, x.cstride, x.coff, wp.data_ptr(), s2)
             call("uh_dw_wgrad_finalize", wp.data_ptr(), wparts, Cp, C, dw.data_ptr(), s2)
         grads[name + ".depthwise.weight"] = dw
         # conv bias in front of train-mode BatchNorm: exactly zero gradient
-        grads[name + ".depthwise.bias"] = self._zeros(C)
+        grads[name + ".depthwise.bias"] = self._gzero(name + ".depthwise.bias", C)
         dx = Ls.act(B, H, W, Cp)
         call("uh_dwconv3x3_dgrad", B, H, W, Cp, dy.ptr, dy.cstride, dy.coff, rec.wt.data_ptr(), C, dr.ptr, dr.cstride,
              dr.coff, mask.data_ptr(), dx.ptr, dx.cstride, dx.coff, s)
@@ -199,9 +219,9 @@ class LUNeXtRun:
         s, Ls = self._sh, self.lease
         S = L.uh_conv_wgrad_splits(Bs, Hs, Ws, cout, K, 1)
         part = Ls.f32(S * cout * K)
-        dw = torch.empty_like(conv.weight)
+        dw = self._gnew(f"downconv{l}.weight", conv.weight.shape)
         with self._side() as s2:
-            grads[f"downconv{l}.bias"] = self._colsum(dy, cout, s2)
+            grads[f"downconv{l}.bias"] = self._colsum(dy, cout, s2, out=self._gnew(f"downconv{l}.bias", (cout,)))
             call("uh_conv_wgrad", Bs, Hs, Ws, dy.ptr, dy.cstride, dy.coff, cout, x4.ptr, x4.cstride, 0, K, 1,
                  part.data_ptr(), s2)
             call("uh_wgrad_reduce_strided", part.data_ptr(), S, cout * K, cout, 4, cin, K, cpi, cin * 4, 1, 4,
@@ -258,12 +278,18 @@ class LUNeXtRun:
                  raw.cstride, raw.coff, s)
             dup = raw
         with self._side() as s2:
-            grads[f"upconv{k}.bias"] = self._colsum(dup, cpo, s2)[:cout]   # a view of a tensor made for this gradient
+            if self.gflat is None:
+                grads[f"upconv{k}.bias"] = self._colsum(dup, cpo, s2)[:cout]   # a view of a tensor made for this gradient
+            elif cpo == cout:
+                grads[f"upconv{k}.bias"] = self._colsum(dup, cpo, s2, out=self.gflat.views[f"upconv{k}.bias"])
+            else:                                                  # padded channels: only the first cout sums are wanted
+                grads[f"upconv{k}.bias"] = self._colsum(dup, cpo, s2, out=self.gflat.views[f"upconv{k}.bias"],
+                                                        cols=self._table(("first", cout), lambda: list(range(cout))))
         d4 = Ls.act(Bs, Hs, Ws, N, tag=f"up{k}.d4")
         call("uh_space_to_depth2", Bs, Hs, Ws, cpo, dup.ptr, dup.cstride, dup.coff, d4.ptr, d4.cstride, 0, s)
         S = L.uh_conv_wgrad_splits(Bs, Hs, Ws, N, cin, 1)
         part = Ls.f32(S * N * cin)
-        dw = torch.empty_like(up.weight)                       # [cin][cout][2][2]
+        dw = self._gnew(f"upconv{k}.weight", up.weight.shape)  # [cin][cout][2][2]
         with self._side() as s2:
             call("uh_conv_wgrad", Bs, Hs, Ws, d4.ptr, d4.cstride, 0, N, x.ptr, x.cstride, x.coff, cin, 1, part.data_ptr(), s2)
             call("uh_wgrad_reduce_strided", part.data_ptr(), S, N * cin, cout, 4, cin, cin, cpo * cin, 4, 1, cout * 4,
@@ -306,14 +332,26 @@ class LUNeXtRun:
         self._zero_used += n
         return out
 
-    def _colsum(self, a, C, s=None):
-        """column sums of `a` (a bias gradient) on stream s (default: the main stream)"""
+    def _gzero(self, name, n):
+        """the gradient of a parameter whose gradient is identically zero: in a flat gradient buffer its place is never
+        written (the buffer starts as zeros), otherwise n zeros out of a per-run buffer"""
+        if self.gflat is not None:
+            return self.gflat.views[name]
+        return self._zeros(n)
+
+    def _colsum(self, a, C, s=None, out=None, cols=None):
+        """column sums of `a` (a bias gradient) on stream s (default: the main stream), into `out` if given; with
+        `cols` (int32 device table) out[i] is the sum of column cols[i]"""
         s, Ls = (self._sh if s is None else s), self.lease
         parts = L.uh_colsum_parts(a.Mp, C)
         cp = Ls.f32(parts * C)
         call("uh_colsum", a.Mp, C, a.ptr, a.cstride, a.coff, cp.data_ptr(), s)
-        out = torch.empty(C, dtype=torch.float32, device=self.device)
-        call("uh_colsum_finalize", cp.data_ptr(), parts, C, 1, out.data_ptr(), 0, s)
+        if out is None:
+            out = torch.empty(C, dtype=torch.float32, device=self.device)
+        if cols is not None:
+            call("uh_colsum_finalize_gather", cp.data_ptr(), parts, C, cols.numel(), cols.data_ptr(), out.data_ptr(), s)
+        else:
+            call("uh_colsum_finalize", cp.data_ptr(), parts, C, 1, out.data_ptr(), 0, s)
         return out
 
     # ------------------------------------------------------------------ attention gate (lunext.py:76-122)
@@ -366,9 +404,23 @@ class LUNeXtRun:
             part = Ls.f32(parts * 216)
             call("uh_gate8_bwd", g.Mp, C, dout.ptr, dout.cstride, dout.coff, g.ptr, g.cstride, g.coff, x.ptr, x.cstride,
                  x.coff, wts.data_ptr(), dg.ptr, dg.cstride, dg.coff, dx.ptr, dx.cstride, dx.coff, part.data_ptr(), s)
+            names = ("sigmoid_conv", "tanh_conv", "combine_conv")
+            if self.gflat is not None:
+                # the three [C][C] weights, then the three biases, lie side by side in the flat buffer
+                # (flat_param_order): one finalisation picks their 3 C (C + 1) sums out of the padded [3][8][8] + [3][8]
+                cols = self._table(("gate8", C), lambda: [64 * j + 8 * r + c for j in range(3) for r in range(C)
+                                                          for c in range(C)] + [192 + 8 * j + c for j in range(3)
+                                                                                for c in range(C)])
+                out = self.gflat.span(pre + "sigmoid_conv.weight", cols.numel())
+                call("uh_colsum_finalize_gather", part.data_ptr(), parts, 216, cols.numel(), cols.data_ptr(),
+                     out.data_ptr(), s)
+                for nm in names:
+                    grads[pre + nm + ".weight"] = self.gflat.views[pre + nm + ".weight"]
+                    grads[pre + nm + ".bias"] = self.gflat.views[pre + nm + ".bias"]
+                return dg, dx
             gw = torch.empty(216, dtype=torch.float32, device=self.device)   # made for these gradients: views below
             call("uh_colsum_finalize", part.data_ptr(), parts, 216, 1, gw.data_ptr(), 0, s)
-            for j, nm in enumerate(("sigmoid_conv", "tanh_conv", "combine_conv")):
+            for j, nm in enumerate(names):
                 grads[pre + nm + ".weight"] = gw[64 * j:64 * j + 64].view(8, 8)[:C, :C].reshape(C, C, 1, 1)
                 grads[pre + nm + ".bias"] = gw[192 + 8 * j:192 + 8 * j + C]
             return dg, dx
@@ -383,9 +435,12 @@ class LUNeXtRun:
         part = Ls.f32(S * 2 * C * C)
         S3 = L.uh_conv_wgrad_splits(B, H, W, C, C, 1)
         part3 = Ls.f32(S3 * C * C)
-        dws = [torch.empty(C, C, 1, 1, dtype=torch.float32, device=self.device) for _ in range(3)]
+        names = ("sigmoid_conv", "tanh_conv", "combine_conv")
+        dws = [self._gnew(pre + nm + ".weight", (C, C, 1, 1)) for nm in names]
         with self._side() as s2:
-            db = self._colsum(dz, 3 * C, s2)
+            # in a flat gradient buffer the three biases lie side by side (flat_param_order)
+            db = self._colsum(dz, 3 * C, s2, out=None if self.gflat is None else
+                              self.gflat.span(pre + "sigmoid_conv.bias", 3 * C))
             call("uh_conv_wgrad", B, H, W, dz.ptr, dz.cstride, 0, 2 * C, g.ptr, g.cstride, g.coff, C, 1,
                  part.data_ptr(), s2)
             for j in range(2):
@@ -448,9 +503,12 @@ class LUNeXtRun:
         self.head_in, self.head_w = cur, w
         return logits
 
-    def backward(self, dlogits):
+    def backward(self, dlogits, gflat=None):
+        """{parameter name: fp32 gradient}.  gflat: a dp.FlatGrads laid out by flat_param_order(module): the gradients
+        are written into its views (those of att*.output_conv, which the forward pass never uses, stay untouched)."""
         if not self.training:
             raise RuntimeError("backward through an eval-mode forward is not built; call model.train() first")
+        self.gflat = gflat
         self._bind_streams()
         m, Ls, s = self.m, self.lease, self._sh
         self.wb = self.packer.get("bwd", s)
@@ -464,10 +522,19 @@ class LUNeXtRun:
         hp = Ls.f32(parts * oc * 9)
         call("uh_head_bwd", B, H, W, 8, oc, a.ptr, a.cstride, a.coff, self.head_w.data_ptr(), dl.data_ptr(), da.ptr,
              da.cstride, da.coff, hp.data_ptr(), s)
-        hw = torch.empty(oc, 9, dtype=torch.float32, device=self.device)    # made for these gradients: views below
-        call("uh_colsum_finalize", hp.data_ptr(), parts, oc * 9, 1, hw.data_ptr(), 0, s)
-        grads["final_conv.weight"] = hw[:, :cin].reshape(oc, cin, 1, 1)
-        grads["final_conv.bias"] = hw[:, 8]
+        if self.gflat is not None:
+            cols = self._table(("head", oc, cin), lambda: [o * 9 + c for o in range(oc) for c in range(cin)] +
+                               [o * 9 + 8 for o in range(oc)])
+            out = self.gflat.span("final_conv.weight", cols.numel())       # weight, then bias: side by side
+            call("uh_colsum_finalize_gather", hp.data_ptr(), parts, oc * 9, cols.numel(), cols.data_ptr(),
+                 out.data_ptr(), s)
+            grads["final_conv.weight"] = self.gflat.views["final_conv.weight"]
+            grads["final_conv.bias"] = self.gflat.views["final_conv.bias"]
+        else:
+            hw = torch.empty(oc, 9, dtype=torch.float32, device=self.device)    # made for these gradients: views below
+            call("uh_colsum_finalize", hp.data_ptr(), parts, oc * 9, 1, hw.data_ptr(), 0, s)
+            grads["final_conv.weight"] = hw[:, :cin].reshape(oc, cin, 1, 1)
+            grads["final_conv.bias"] = hw[:, 8]
         skip_grads = [None] * 4
         self._skip_ready = {}
         for k in range(4, 0, -1):
@@ -489,6 +556,23 @@ class LUNeXtRun:
     def release(self):
         self.recs, self.saved = {}, {}
         self.lease.release()
+
+
+def flat_param_order(module):
+    """Parameter names in the order a flat gradient buffer must hold them for LUNeXtRun.backward(gflat=...): declaration
+    order, except that each attention gate's three used 1x1 weights come first, then its three biases, so that the
+    tensors one kernel pass produces together lie side by side."""
+    order = []
+    for n, _ in module.named_parameters():
+        if n.startswith("att") and ".output_conv." not in n:
+            pre = n.split(".")[0]
+            if n == pre + ".sigmoid_conv.weight":
+                order += [f"{pre}.{c}.weight" for c in ("sigmoid_conv", "tanh_conv", "combine_conv")]
+                order += [f"{pre}.{c}.bias" for c in ("sigmoid_conv", "tanh_conv", "combine_conv")]
+            continue
+        order.append(n)
+    assert sorted(order) == sorted(n for n, _ in module.named_parameters())
+    return order
 
 
 class _LUNeXtFn(torch.autograd.Function):

@@ -225,30 +225,19 @@ def train_model(train_data, validation_data, model_type="UNet", epochs=50, batch
         train_step = stepper.train_step
         rank, world = stepper.rank, stepper.world
     else:
-        opt = torch.optim.Adam(model.parameters(), lr=learning_rate, fused=True)
-        get_lr = lambda: opt.param_groups[0]["lr"]                           # noqa: E731
-
-        def set_lr(v):
-            for g in opt.param_groups:
-                g["lr"] = v
-
-        from .dp import GradAverager
-        joined = data_parallel and torch.distributed.is_initialized()
-        averager = GradAverager(model.parameters()) if joined else None
-        if averager is not None:
-            averager.broadcast_from_rank0(model)
-
-        def train_step(images, masks):
-            model.train()
-            opt.zero_grad(set_to_none=True)
-            loss = loss_fn(model(images), masks)
-            loss.backward()
-            if averager is not None:
-                averager.average()              # mean of the per-shard gradients, as for the U-Net
-            opt.step()
-            return loss.detach()
-        rank = torch.distributed.get_rank() if joined else 0
-        world = torch.distributed.get_world_size() if joined else 1
+        from .dp import LUNeXtTrainer
+        if custom_loss == "cl_dice":
+            crit = "cl_dice"                       # sigmoid + clamp + clDice, value and gradient from the kernels
+        elif custom_loss is None:
+            crit = "bce"
+        else:
+            crit = loss_fn                         # any other criterion: differentiated by autograd at the logits
+        stepper = LUNeXtTrainer(model, lr=learning_rate, criterion=crit, standalone=not data_parallel)
+        opt = stepper.optimizer
+        get_lr = lambda: opt.lr                                              # noqa: E731
+        set_lr = lambda v: setattr(opt, "lr", v)                             # noqa: E731
+        train_step = stepper.train_step
+        rank, world = stepper.rank, stepper.world
     scheduler = PlateauLR(get_lr, set_lr, patience=5, factor=0.5)
 
     n_train, n_val = len(ds_tr), len(ds_va)
