@@ -110,3 +110,38 @@ def test_backward_strip_walk_equals_tile_kernel(B, H, W, monkeypatch):
         (got,) = torch.autograd.grad(crit(mask, probs) * 2.5, probs)
         assert torch.equal(got, want), (R, (got - want).abs().max().item())
     assert want.abs().max().item() > 0
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 7, 5), (1, 64, 40), (2, 33, 41), (1, 50, 117), (3, 100, 76), (2, 256, 256)])
+def test_forward_strip_walk_equals_level_kernels(B, H, W, monkeypatch):
+    """The soft skeleton has two forward paths: all eleven levels in one strip walk (default; a wave per 40-column strip
+    with a 12-column halo) and one launch per level (UNET_AMD_SKEL_FWD=0).  Same operations, so: the same skeleton,
+    the same loss, and (through the saved E / skel planes the backward pass reads) the same gradient, bit for bit, on
+    widths around the strip width, heights no strip length divides, tie-heavy inputs and several strip lengths."""
+    g = torch.Generator().manual_seed(H * 1000 + W + 1)
+    mask = (torch.rand(B, 1, H, W, generator=g) > 0.55).float().to(DEV)
+    probs = torch.rand(B, 1, H, W, generator=g)
+    probs[0] = (probs[0] * 8).round() / 8
+    if B > 1:
+        probs[1, :, :, : W // 2] = 1.0
+    probs = probs.clamp(1e-6, 1 - 1e-6).to(DEV).requires_grad_(True)
+    crit = unet_amd.soft_dice_cldice()
+    sk = unet_amd.SoftSkeletonize(num_iter=10, check_range=False)
+
+    def everything():
+        loss = crit(mask, probs)
+        (grad,) = torch.autograd.grad(loss, probs)
+        return loss.detach().clone(), grad, sk(probs.detach()), sk(mask)
+
+    monkeypatch.setenv("UNET_AMD_SKEL_FWD", "0")
+    want = everything()
+    monkeypatch.delenv("UNET_AMD_SKEL_FWD")
+    for R in (None, "1", "7", "16", "100"):
+        if R is None:
+            monkeypatch.delenv("UNET_AMD_SKEL_FWD_R", raising=False)
+        else:
+            monkeypatch.setenv("UNET_AMD_SKEL_FWD_R", R)
+        got = everything()
+        for a, b, what in zip(got, want, ("loss", "gradient", "skeleton of the prediction", "skeleton of the mask")):
+            assert torch.equal(a, b), (R, what, (a - b).abs().max().item())
+    assert want[2].abs().max().item() > 0

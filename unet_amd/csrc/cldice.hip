@@ -647,6 +647,123 @@ __global__ __launch_bounds__(256) void skel_bwd_strip_kernel(BwdArgs a, int plan
   }
 }
 
+// ---- forward, strip walk over several levels at once -----------------------------------------------------------------
+// NLEV consecutive levels k0 .. k0+NLEV-1 of the chain in one pass, as a register pipeline down a strip of 64 columns
+// (NLEV+1 halo columns on either side, lane = column): with row t of E_{k0} just arrived, E_{k0+j} is evaluated for row
+// t-j (j = 1..NLEV), delta and skel of level k0+j for row t-j-2.  The skeleton value of a pixel travels from level to
+// level, one level per iteration.  Every operation is the one skel_level_kernel performs (min / max are exact, the
+// skeleton update has the same two roundings), so the planes are bit-identical to those of the level-by-level kernels;
+// what changes is the traffic: E_{k0} and skel_{k0-1} are read once, and only what a later pass needs is written
+// (KEEP: every E and skel plane, for the backward pass; otherwise the last skeleton and, if asked for, the last E).
+struct FwdArgs {
+  const float* in;       // E_{k0}; the raw input when FIRST (clamped on the fly)
+  const float* sk_in;    // skel_{k0-1}; unused when FIRST
+  float* e_out;          // KEEP: plane set of E_{k0+1}, those of the following levels n floats apart;
+                         // otherwise the plane set of E_{k0+NLEV}, or null
+  float* sk_out;         // KEEP: plane set of skel_{k0}, the following n floats apart; otherwise that of skel_{k0+NLEV-1}
+  long long n;           // floats per plane set
+  int H, W, planes;
+};
+
+template <int NLEV, bool FIRST, bool KEEP>
+__global__ __launch_bounds__(256) void skel_fwd_strip_kernel(FwdArgs a, int R, int nstrips, int nchunks) {
+  constexpr int HALO = NLEV + 1, CORE = 64 - 2 * HALO;
+  const int lane = threadIdx.x & 63;
+  const unsigned per_xcd = gridDim.x >> 3;                 // XCD-contiguous strips, as in skel_bwd_strip_kernel
+  const unsigned lblk = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  unsigned item = lblk * 4u + (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (item >= (unsigned)a.planes * nstrips * nchunks) return;
+  const int chunk = (int)(item % (unsigned)nchunks);
+  item /= (unsigned)nchunks;
+  const int strip = (int)(item % (unsigned)nstrips);
+  const long long plane = (long long)(item / (unsigned)nstrips) * a.H * a.W;
+  const int H = a.H, W = a.W;
+  const int Y0 = chunk * R, Y1 = (Y0 + R < H) ? Y0 + R : H;
+  const int x = strip * CORE - HALO + lane;
+  const bool inx = x >= 0 && x < W;
+  const bool core = inx && lane >= HALO && lane < 64 - HALO;
+  const long long col = plane + (inx ? x : 0);
+  const float* __restrict__ p_in = a.in + col;
+  const float* __restrict__ p_sk = FIRST ? nullptr : a.sk_in + col;
+  auto ld_raw = [&](const float* __restrict__ p, int y) -> float {
+    const bool ok = (y >= 0) & (y < H);
+    return p[(ok ? y : 0) * W];
+  };
+  auto rowin = [&](int y) -> bool { return (y >= 0) & (y < H); };
+  // rings of three rows, slot = row mod 3 in terms of the iteration's phase (see skel_bwd_strip_kernel)
+  float ec[NLEV + 1][3];        // E_{k0+j}, +inf outside the image (an erosion ignores it)
+  float hm[NLEV + 1][3];        // max over (x-1, x, x+1) of E_{k0+j}, -inf outside the image (a dilation ignores it)
+  float skc[NLEV];              // skel_{k0+j} of the row level j handled in the previous iteration
+#pragma unroll
+  for (int j = 0; j <= NLEV; ++j)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      ec[j][q] = INFINITY;
+      hm[j][q] = -INFINITY;
+    }
+#pragma unroll
+  for (int j = 0; j < NLEV; ++j) skc[j] = 0.f;
+  const int t0 = Y0 - HALO, t1 = Y1 - 1 + HALO;
+  float q_in = ld_raw(p_in, t0);
+  float q_sk = FIRST ? 0.f : ld_raw(p_sk, t0 - 2);
+
+  auto body = [&](auto phase, int t) {
+    constexpr int PH = decltype(phase)::value;
+    const float n_in = ld_raw(p_in, t + 1);
+    const float n_sk = FIRST ? 0.f : ld_raw(p_sk, t - 1);
+    {
+      const float v = FIRST ? clamp01(q_in) : q_in;
+      ec[0][PH % 3] = (rowin(t) & inx) ? v : INFINITY;
+    }
+    float below = (rowin(t - 2) & inx) ? q_sk : 0.f;      // skel of the level below for the row level 0 handles now
+#pragma unroll
+    for (int j = 0; j < NLEV; ++j) {
+      // E_{j}: rows t-j (slot N), t-j-1 (M), t-j-2 (O)
+      // (constants once the loop is unrolled)
+      const int N = ((PH - j) % 3 + 3) % 3, M = (N + 2) % 3, O = (N + 1) % 3;
+      const int N1 = ((PH - j - 1) % 3 + 3) % 3;          // where E_{j+1} keeps its new row t-j-1
+      const float mid = ec[j][M];
+      float e1 = fminf(fminf(ec[j][O], ec[j][N]), fminf(mid, fminf(from_left(mid), from_right(mid))));
+      const int r1 = t - j - 1;
+      const bool in1 = rowin(r1) & inx;
+      e1 = in1 ? e1 : INFINITY;
+      ec[j + 1][N1] = e1;
+      const float d = in1 ? e1 : -INFINITY;
+      hm[j + 1][N1] = fmaxf(d, fmaxf(from_left(d), from_right(d)));
+      const bool st1 = core & (r1 >= Y0) & (r1 < Y1);
+      if (KEEP) {
+        if (st1) a.e_out[(long long)j * a.n + plane + (long long)r1 * W + x] = e1;
+      } else if (j == NLEV - 1 && a.e_out) {
+        if (st1) a.e_out[plane + (long long)r1 * W + x] = e1;
+      }
+      // level j's delta and skeleton for row y = t-j-2
+      const int y = t - j - 2;
+      const float D = fmaxf(fmaxf(hm[j + 1][0], hm[j + 1][1]), hm[j + 1][2]);
+      const float delta = fmaxf(ec[j][O] - D, 0.f);
+      float sv = delta;
+      if (!(FIRST && j == 0)) {
+        const float prod = below * delta;
+        sv = below + fmaxf(delta - prod, 0.f);
+      }
+      below = skc[j];            // what level j made in the previous iteration: the row level j+1 handles now
+      skc[j] = sv;
+      const bool st = core & (y >= Y0) & (y < Y1);
+      if (KEEP) {
+        if (st) a.sk_out[(long long)j * a.n + plane + (long long)y * W + x] = sv;
+      } else if (j == NLEV - 1) {
+        if (st) a.sk_out[plane + (long long)y * W + x] = sv;
+      }
+    }
+    q_in = n_in;
+    q_sk = n_sk;
+  };
+  for (int t = t0; t <= t1; t += 3) {
+    body(std::integral_constant<int, 0>{}, t);
+    if (t + 1 <= t1) body(std::integral_constant<int, 1>{}, t + 1);
+    if (t + 2 <= t1) body(std::integral_constant<int, 2>{}, t + 2);
+  }
+}
+
 // ---- host entry points ----------------------------------------------------------------------------------------
 static int grid_for(long long n) {
   long long b = (n + 255) / 256;
@@ -675,6 +792,34 @@ extern "C" int uh_soft_dilate(int planes, int H, int W, const float* in, float* 
 // keep_all = 0: three rotating E buffers and one skeleton plane (E needs 3n floats, SK n floats).
 static int skel_forward(int planes, int H, int W, const float* x, float* E, float* SK, int keep_all, hipStream_t st) {
   const long long n = (long long)planes * H * W;
+  // UNET_AMD_SKEL_FWD=0: one launch per level (skel_level kernels below) instead of the whole chain in one strip walk;
+  // both give the same bits.  UNET_AMD_SKEL_FWD_R: core rows per strip-walk wave.
+  const char* env = getenv("UNET_AMD_SKEL_FWD");
+  if ((!env || atoi(env) != 0) && (long long)H * W < (1ll << 31)) {
+    constexpr int CORE = 64 - 2 * (SKEL_LEVELS + 1);
+    const int nstrips = uh_cdiv(W, CORE);
+    int R = 32;
+    if (const char* e = getenv("UNET_AMD_SKEL_FWD_R")) R = atoi(e) > 0 ? atoi(e) : R;
+    const int nchunks = uh_cdiv(H, R);
+    const long long items = (long long)planes * nstrips * nchunks;
+    if (items < (1ll << 32)) {
+      const dim3 sgrid((unsigned)(((items + 3) / 4 + 7) / 8 * 8));
+      FwdArgs a;
+      a.in = x;
+      a.sk_in = nullptr;
+      a.e_out = keep_all ? E : nullptr;
+      a.sk_out = SK;
+      a.n = n;
+      a.H = H;
+      a.W = W;
+      a.planes = planes;
+      if (keep_all)
+        hipLaunchKernelGGL((skel_fwd_strip_kernel<SKEL_LEVELS, true, true>), sgrid, dim3(256), 0, st, a, R, nstrips, nchunks);
+      else
+        hipLaunchKernelGGL((skel_fwd_strip_kernel<SKEL_LEVELS, true, false>), sgrid, dim3(256), 0, st, a, R, nstrips, nchunks);
+      return uh_check_launch("soft_skel");
+    }
+  }
   const int grid = grid_for(n);
   // four pixels per thread when rows are multiples of 4 pixels, every plane set is 16-byte aligned and the
   // item count fits 32 bits
