@@ -165,6 +165,34 @@ int uh_bn_relu_bwd_reduce(long long Mp, int C, const void* da, int da_cstride, i
  * (C entries each) */
 int uh_bn_bwd_finalize(const float* partial, int P, int C, int c_real, long long count,
                        float* dgamma, float* dbeta, float* coef, int accumulate, uh_stream s);
+
+/* ---- the same sums, finalised inside the launch that takes them ------------------------------------------------------
+ * The last workgroups to finish add up the per-workgroup rows (fixed order, fp64: run-independent results) and
+ * evaluate the per-channel result, so no finalisation launch follows.  ws: uh_fin_ws_bytes(parts, C, 2) bytes, 8-byte
+ * aligned, `parts` the workgroup count of the launch (uh_bn_bwd_parts / uh_dw_parts); counters: uh_fin_counters()
+ * unsigned ints, zero before the first such launch on a stream; every launch leaves them zero.  Launches that share
+ * counters must be ordered on one stream. */
+size_t uh_fin_ws_bytes(int parts, int C, int nstat);
+int uh_fin_counters(void);
+/* uh_bn_relu_bwd_reduce + uh_bn_bwd_finalize (autograd of BatchNorm2d + ReLU, unet.py:19-76) */
+int uh_bn_relu_bwd_reduce_fin(long long Mp, int C, const void* da, int da_cstride, int da_coff, const void* y,
+                              int y_cstride, int y_coff, const float* mean, const float* invstd, const float* scale,
+                              const float* shift, int c_real, long long count, float* dgamma, float* dbeta, float* coef,
+                              void* ws, size_t ws_bytes, unsigned* counters, uh_stream s);
+/* uh_bn_res_relu_bwd_reduce + uh_bn_bwd_finalize (autograd of DepthwiseConvBlock's BatchNorm + residual + ReLU,
+ * lunext.py:19-30) */
+int uh_bn_res_relu_bwd_reduce_fin(long long Mp, int C, const void* da, int da_cstride, int da_coff, const void* y,
+                                  int y_cstride, int y_coff, const void* x, int x_cstride, int x_coff,
+                                  const float* mean, const float* invstd, const float* scale, const float* shift,
+                                  int c_real, long long count, float* dgamma, float* dbeta, float* coef, void* ws,
+                                  size_t ws_bytes, unsigned* counters, uh_stream s);
+/* uh_dwconv3x3_fwd in train mode + uh_bn_finalize (lunext.py:14-21: depthwise conv, then BatchNorm's batch statistics,
+ * scale / shift and running-statistics update) */
+int uh_dwconv3x3_fwd_bn(int B, int H, int W, int C, const void* x, int x_cstride, int x_coff, const float* w, int c_real,
+                        const float* bias, const uint8_t* rowmask, void* out, int o_cstride, int o_coff,
+                        const float* gamma, const float* beta, float eps, float momentum, float* mean, float* invstd,
+                        float* scale, float* shift, float* running_mean, float* running_var, long long* nbt, void* ws,
+                        size_t ws_bytes, unsigned* counters, uh_stream s);
 /* dy = scale * (dyh - coef0 - xhat*coef1) on interior rows, 0 on pads */
 int uh_bn_relu_bwd_apply(long long Mp, int C, const void* da, int da_cstride, int da_coff,
                          const void* y, int y_cstride, int y_coff,

@@ -1040,3 +1040,116 @@ def test_flat_adam_under_grad_scaler_matches_torch():
     assert opt._steps_dev.item() == 3.0
     # the flat gradient the scaler walked is the one buffer: its inf check saw every parameter's gradient
     assert opt.param_groups[0]["params"][0].grad.data_ptr() == opt.g.data_ptr()
+
+
+def _fin_ws(parts, C):
+    nbytes = lib.uh_fin_ws_bytes(parts, C, 2)
+    return torch.full(((nbytes + 7) // 8,), float("nan"), dtype=torch.float64, device=DEV), nbytes
+
+
+@pytest.mark.parametrize("B,H,W,C,c_real", [(2, 8, 8, 64, 64), (1, 4, 12, 128, 128), (2, 96, 80, 64, 64), (3, 2, 2, 512, 512),
+                                            (8, 64, 64, 8, 3), (1, 2, 2, 1024, 1024)])
+def test_sums_finalised_inside_the_launch_equal_the_two_launch_form(B, H, W, C, c_real):
+    """uh_bn_relu_bwd_reduce_fin / uh_bn_res_relu_bwd_reduce_fin (the last workgroups of the launch add the partial rows
+    up and write dgamma, dbeta and the two coefficients) against reduce + uh_bn_bwd_finalize: both add the same rows in
+    fp64, in different groupings, so results agree to fp32 rounding; three runs in a row give identical bits (who adds
+    depends on timing, what is added does not), leave the arrival counters zero, and write nothing past c_real."""
+    g = torch.Generator().manual_seed(B * 7 + C)
+    ya, st = _bn_bwd_setup(g, B, C, H, W)
+    da = act_from(bf(torch.randn(B, C, H, W, generator=g)))
+    xa = act_from(bf(torch.randn(B, C, H, W, generator=g)))
+    count = B * H * W
+    counters = torch.zeros(lib.uh_fin_counters(), dtype=torch.int32, device=DEV)
+    parts = lib.uh_bn_bwd_parts(da.Mp, C)
+    for residual in (False, True):
+        rp = torch.empty(parts, 2, C, device=DEV)
+        if residual:
+            call("uh_bn_res_relu_bwd_reduce", da.Mp, C, da.ptr, da.cstride, da.coff, ya.ptr, ya.cstride, ya.coff, xa.ptr,
+                 xa.cstride, xa.coff, *[t.data_ptr() for t in st], rp.data_ptr(), S())
+        else:
+            call("uh_bn_relu_bwd_reduce", da.Mp, C, da.ptr, da.cstride, da.coff, ya.ptr, ya.cstride, ya.coff,
+                 *[t.data_ptr() for t in st], rp.data_ptr(), S())
+        want = [torch.full((c_real + 2,), 9.0, device=DEV), torch.full((c_real + 2,), 9.0, device=DEV),
+                torch.empty(2 * C, device=DEV)]
+        call("uh_bn_bwd_finalize", rp.data_ptr(), parts, C, c_real, count, want[0].data_ptr(), want[1].data_ptr(),
+             want[2].data_ptr(), 0, S())
+        runs = []
+        for _ in range(3):
+            ws, nbytes = _fin_ws(parts, C)
+            got = [torch.full((c_real + 2,), 9.0, device=DEV), torch.full((c_real + 2,), 9.0, device=DEV),
+                   torch.full((2 * C,), float("nan"), device=DEV)]
+            tail = (c_real, count, got[0].data_ptr(), got[1].data_ptr(), got[2].data_ptr(), ws.data_ptr(), nbytes,
+                    counters.data_ptr(), S())
+            if residual:
+                call("uh_bn_res_relu_bwd_reduce_fin", da.Mp, C, da.ptr, da.cstride, da.coff, ya.ptr, ya.cstride, ya.coff,
+                     xa.ptr, xa.cstride, xa.coff, *[t.data_ptr() for t in st], *tail)
+            else:
+                call("uh_bn_relu_bwd_reduce_fin", da.Mp, C, da.ptr, da.cstride, da.coff, ya.ptr, ya.cstride, ya.coff,
+                     *[t.data_ptr() for t in st], *tail)
+            torch.cuda.synchronize()
+            assert counters.abs().sum().item() == 0
+            runs.append(got)
+        for a, b in zip(runs[0], runs[1]):
+            assert torch.equal(a, b)
+        for a, b in zip(runs[0], runs[2]):
+            assert torch.equal(a, b)
+        scale = max(w.abs().max().item() for w in want[:2])
+        for a, w, what in zip(runs[0], want, ("dgamma", "dbeta", "coef")):
+            assert torch.isfinite(a).all(), what
+            assert (a - w).abs().max().item() <= 2e-6 * max(scale, w.abs().max().item()) + 1e-9, what
+        assert runs[0][0][c_real:].tolist() == [9.0, 9.0] and runs[0][1][c_real:].tolist() == [9.0, 9.0]
+    with pytest.raises(_lib.HipKernelError):
+        ws, nbytes = _fin_ws(parts, C)
+        call("uh_bn_relu_bwd_reduce_fin", da.Mp, C, da.ptr, da.cstride, da.coff, ya.ptr, ya.cstride, ya.coff,
+             *[t.data_ptr() for t in st], c_real, count, want[0].data_ptr(), want[1].data_ptr(), want[2].data_ptr(),
+             ws.data_ptr(), nbytes - 8, counters.data_ptr(), S())
+
+
+@pytest.mark.parametrize("B,H,W,C,c_real", [(2, 16, 16, 64, 64), (4, 64, 64, 8, 3), (3, 5, 7, 24, 24), (2, 128, 128, 64, 64),
+                                            (1, 48, 48, 512, 512)])
+def test_depthwise_forward_with_batchnorm_finalised_inside(B, H, W, C, c_real):
+    """uh_dwconv3x3_fwd_bn against uh_dwconv3x3_fwd (train mode) + uh_bn_finalize: the same fp16 output bit for bit;
+    mean, invstd, scale, shift and the running statistics to fp32 rounding; num_batches_tracked counted once."""
+    g = torch.Generator().manual_seed(B + H + C)
+    x = bf(torch.randn(B, C, H, W, generator=g))
+    if c_real < C:
+        x[:, c_real:] = 0
+    xa = act_from(x)
+    w = (torch.randn(c_real, 1, 3, 3, generator=g) / 3).to(DEV)
+    bias = torch.randn(c_real, generator=g).to(DEV)
+    gamma, beta = (torch.rand(c_real, generator=g) + 0.5).to(DEV), torch.randn(c_real, generator=g).to(DEV)
+    mask = rowmask(B, H, W)
+    parts = lib.uh_dw_parts(B, H, W, C)
+    counters = torch.zeros(lib.uh_fin_counters(), dtype=torch.int32, device=DEV)
+
+    def fresh():
+        return dict(y=new_act(B, H, W, C, DEV), f=torch.full((4, C), float("nan"), device=DEV),
+                    rm=torch.zeros(c_real, device=DEV), rv=torch.ones(c_real, device=DEV),
+                    nbt=torch.zeros((), dtype=torch.int64, device=DEV))
+    a = fresh()
+    stat = torch.empty(parts, 2, C, device=DEV)
+    call("uh_dwconv3x3_fwd", B, H, W, C, xa.ptr, xa.cstride, xa.coff, w.data_ptr(), c_real, bias.data_ptr(),
+         _lib.EPI_RAW_STATS, None, None, mask.data_ptr(), a["y"].ptr, a["y"].cstride, a["y"].coff, stat.data_ptr(), S())
+    call("uh_bn_finalize", stat.data_ptr(), parts, C, c_real, B * H * W, gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.1,
+         a["f"][0].data_ptr(), a["f"][1].data_ptr(), a["f"][2].data_ptr(), a["f"][3].data_ptr(), a["rm"].data_ptr(),
+         a["rv"].data_ptr(), a["nbt"].data_ptr(), S())
+    outs = []
+    for _ in range(2):
+        b = fresh()
+        ws, nbytes = _fin_ws(parts, C)
+        call("uh_dwconv3x3_fwd_bn", B, H, W, C, xa.ptr, xa.cstride, xa.coff, w.data_ptr(), c_real, bias.data_ptr(),
+             mask.data_ptr(), b["y"].ptr, b["y"].cstride, b["y"].coff, gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.1,
+             b["f"][0].data_ptr(), b["f"][1].data_ptr(), b["f"][2].data_ptr(), b["f"][3].data_ptr(), b["rm"].data_ptr(),
+             b["rv"].data_ptr(), b["nbt"].data_ptr(), ws.data_ptr(), nbytes, counters.data_ptr(), S())
+        torch.cuda.synchronize()
+        assert counters.abs().sum().item() == 0
+        outs.append(b)
+    b = outs[0]
+    assert torch.equal(b["y"].buf, a["y"].buf)
+    assert b["nbt"].item() == 1 and a["nbt"].item() == 1
+    for k in ("f", "rm", "rv"):
+        assert torch.equal(outs[0][k], outs[1][k]), k                       # run-independent
+        torch.testing.assert_close(b[k], a[k], rtol=3e-6, atol=1e-6)
+    assert torch.isfinite(b["f"]).all()
+    if c_real < C:                                                           # padding channels: scale = shift = 0
+        assert b["f"][2, c_real:].abs().max().item() == 0 and b["f"][3, c_real:].abs().max().item() == 0

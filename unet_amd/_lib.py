@@ -50,6 +50,11 @@ SIGNATURES = {
     "uh_bn_bwd_parts": (I, [L, I]),
     "uh_bn_relu_bwd_reduce": (I, [L, I, P, I, I, P, I, I, P, P, P, P, P, P]),
     "uh_bn_bwd_finalize": (I, [P, I, I, I, L, P, P, P, I, P]),
+    "uh_fin_ws_bytes": (Z, [I, I, I]),
+    "uh_fin_counters": (I, []),
+    "uh_bn_relu_bwd_reduce_fin": (I, [L, I, P, I, I, P, I, I, P, P, P, P, I, L, P, P, P, P, Z, P, P]),
+    "uh_bn_res_relu_bwd_reduce_fin": (I, [L, I, P, I, I, P, I, I, P, I, I, P, P, P, P, I, L, P, P, P, P, Z, P, P]),
+    "uh_dwconv3x3_fwd_bn": (I, [I, I, I, I, P, I, I, P, I, P, P, P, I, I, P, P, F, F, P, P, P, P, P, P, P, P, Z, P, P]),
     "uh_bn_relu_bwd_apply": (I, [L, I, P, I, I, P, I, I, P, P, P, P, P, P, P, I, I, P]),
     "uh_maxpool2_fwd": (I, [I, I, I, I, P, I, I, P, I, I, P]),
     "uh_maxpool2_bwd": (I, [I, I, I, I, P, I, I, P, I, I, P, I, I, P, I, I, P]),

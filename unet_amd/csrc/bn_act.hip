@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(long long Mp, i
                                                                  const float* __restrict__ invstd,
                                                                  const float* __restrict__ scale,
                                                                  const float* __restrict__ shift,
-                                                                 float* __restrict__ partial) {
+                                                                 float* __restrict__ partial, BnBwdFin fin) {
   extern __shared__ float lds[];
   const int cpr = C / 8, rpi = 256 / cpr;
   const int rr = threadIdx.x / cpr, cc = threadIdx.x % cpr;
@@ -166,7 +166,12 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(long long Mp, i
     }
     if (m < Mp) row(*(const U4*)(da + (m * da_cs + da_co + cc * 8) * 2), *(const U4*)(y + (m * y_cs + y_co + cc * 8) * 2));
   }
-  block_combine_store<2>(acc, C, cpr, rpi, lds, partial + (long long)blockIdx.x * 2 * C);
+  if (fin.ws.counters) {
+    block_combine_store<2, true>(acc, C, cpr, rpi, lds, partial + (long long)blockIdx.x * 2 * C);
+    last_arriver_finish<2>(partial, C, fin.ws, fin);
+  } else {
+    block_combine_store<2>(acc, C, cpr, rpi, lds, partial + (long long)blockIdx.x * 2 * C);
+  }
 }
 
 extern "C" int uh_bn_relu_bwd_reduce(long long Mp, int C, const void* da, int da_cstride, int da_coff, const void* y,
@@ -175,10 +180,44 @@ extern "C" int uh_bn_relu_bwd_reduce(long long Mp, int C, const void* da, int da
   EW_CHECK("bn_relu_bwd_reduce", C);
   UH_REQUIRE(Mp > 0 && da && y && mean && invstd && scale && shift && partial, "bn_relu_bwd_reduce: bad arguments");
   const int rpi = ew_rows_per_iter(C);
+  BnBwdFin fin{};
   hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3(ew_stat_blocks(Mp, C)), dim3(256), (size_t)rpi * 2 * C * 4,
                      (hipStream_t)s, Mp, C, (const char*)da, da_cstride, da_coff, (const char*)y, y_cstride, y_coff,
-                     mean, invstd, scale, shift, partial);
+                     mean, invstd, scale, shift, partial, fin);
   return uh_check_launch("bn_relu_bwd_reduce");
+}
+
+// ---- workspace of the launches that finalise their own sums (ew.h: last_arriver_finish) ----------------------------
+// ws: uh_fin_ws_bytes(parts, C, nstat) bytes = the group rows (fp64) followed by the partial rows (fp32);
+// counters: UH_FIN_COUNTERS unsigned ints, zero before the first such launch on a stream and left zero by each
+extern "C" size_t uh_fin_ws_bytes(int parts, int C, int nstat) { return fin_ws_bytes(parts, C, nstat); }
+extern "C" int uh_fin_counters() { return FIN_MAX_COUNTERS; }
+
+extern "C" int uh_bn_relu_bwd_reduce_fin(long long Mp, int C, const void* da, int da_cstride, int da_coff,
+                                         const void* y, int y_cstride, int y_coff, const float* mean,
+                                         const float* invstd, const float* scale, const float* shift, int c_real,
+                                         long long count, float* dgamma, float* dbeta, float* coef, void* ws,
+                                         size_t ws_bytes, unsigned* counters, uh_stream s) {
+  EW_CHECK("bn_relu_bwd_reduce_fin", C);
+  UH_REQUIRE(Mp > 0 && da && y && mean && invstd && scale && shift && dgamma && dbeta && coef && count > 0 &&
+                 c_real > 0 && c_real <= C,
+             "bn_relu_bwd_reduce_fin: bad arguments");
+  const int parts = ew_stat_blocks(Mp, C);
+  BnBwdFin fin{};
+  float* partial = nullptr;
+  UH_REQUIRE(fin_split(parts, C, 2, ws, ws_bytes, counters, fin.ws, partial),
+             "bn_relu_bwd_reduce_fin: workspace of %zu bytes (8-byte aligned) and counters needed", uh_fin_ws_bytes(parts, C, 2));
+  fin.count = (double)count;
+  fin.dgamma = dgamma;
+  fin.dbeta = dbeta;
+  fin.coef = coef;
+  fin.c_real = c_real;
+  fin.C = C;
+  const int rpi = ew_rows_per_iter(C);
+  hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3(parts), dim3(256), (size_t)rpi * 2 * C * 4, (hipStream_t)s, Mp, C,
+                     (const char*)da, da_cstride, da_coff, (const char*)y, y_cstride, y_coff, mean, invstd, scale, shift,
+                     partial, fin);
+  return uh_check_launch("bn_relu_bwd_reduce_fin");
 }
 
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int P, int C,

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(long long Mp, int C, in
                                                          const float* __restrict__ scale,
                                                          const float* __restrict__ shift,
                                                          const uint8_t* __restrict__ rowmask, char* __restrict__ out,
-                                                         int o_cs, int o_co, float* __restrict__ partial) {
+                                                         int o_cs, int o_co, float* __restrict__ partial, BnFwdFin fin) {
   extern __shared__ float lds[];
   const DwGeo g = dw_geo(Mp, C, Wp);
   float acc[2][8];
@@ -172,7 +172,14 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(long long Mp, int C, in
       mp += Wp;
     }
   }
-  if (MODE == UH_EPI_RAW_STATS) block_combine_store<2>(acc, C, g.cpr, g.xt, lds, partial + (long long)blockIdx.x * 2 * C);
+  if (MODE == UH_EPI_RAW_STATS) {
+    if (fin.ws.counters) {                                  // BatchNorm scale / shift right here
+      block_combine_store<2, true>(acc, C, g.cpr, g.xt, lds, partial + (long long)blockIdx.x * 2 * C);
+      last_arriver_finish<2>(partial, C, fin.ws, fin);
+    } else {
+      block_combine_store<2>(acc, C, g.cpr, g.xt, lds, partial + (long long)blockIdx.x * 2 * C);
+    }
+  }
 }
 
 extern "C" int uh_dw_parts(int B, int H, int W, int C) {
@@ -192,15 +199,56 @@ extern "C" int uh_dwconv3x3_fwd(int B, int H, int W, int C, const void* x, int x
   UH_REQUIRE(mode != UH_EPI_AFFINE_RELU || (scale && shift), "dwconv3x3_fwd: AFFINE_RELU needs scale/shift");
   const long long Mp = uh_mp(B, H, W);
   const int rpi = ew_rows_per_iter(C);
+  BnFwdFin fin{};
   if (mode == UH_EPI_RAW_STATS)
     hipLaunchKernelGGL(dwconv_fwd_kernel<UH_EPI_RAW_STATS>, dw_grid(B, H, W, C), dim3(256), (size_t)rpi * 2 * C * 4,
                        (hipStream_t)s, Mp, C, W + 1, (const char*)x, x_cstride, x_coff, w, c_real, bias, scale, shift,
-                       rowmask, (char*)out, o_cstride, o_coff, partial);
+                       rowmask, (char*)out, o_cstride, o_coff, partial, fin);
   else
     hipLaunchKernelGGL(dwconv_fwd_kernel<UH_EPI_AFFINE_RELU>, dw_grid(B, H, W, C), dim3(256), 0, (hipStream_t)s, Mp, C,
                        W + 1, (const char*)x, x_cstride, x_coff, w, c_real, bias, scale, shift, rowmask, (char*)out,
-                       o_cstride, o_coff, partial);
+                       o_cstride, o_coff, partial, fin);
   return uh_check_launch("dwconv3x3_fwd");
+}
+
+// The train-mode launch that also finalises its BatchNorm statistics (what uh_bn_finalize would do behind it), in the
+// last workgroups to finish (ew.h: last_arriver_finish).  ws / counters: uh_fin_ws_bytes(uh_dw_parts(..), C, 2),
+// uh_fin_counters().
+extern "C" int uh_dwconv3x3_fwd_bn(int B, int H, int W, int C, const void* x, int x_cstride, int x_coff, const float* w,
+                                   int c_real, const float* bias, const uint8_t* rowmask, void* out, int o_cstride,
+                                   int o_coff, const float* gamma, const float* beta, float eps, float momentum,
+                                   float* mean, float* invstd, float* scale, float* shift, float* running_mean,
+                                   float* running_var, long long* nbt, void* ws, size_t ws_bytes, unsigned* counters,
+                                   uh_stream s) {
+  EW_CHECK("dwconv3x3_fwd_bn", C);
+  UH_REQUIRE(B > 0 && H > 0 && W > 0 && x && w && rowmask && out && gamma && beta && mean && invstd && scale && shift,
+             "dwconv3x3_fwd_bn: bad arguments");
+  UH_REQUIRE(c_real > 0 && c_real <= C && ((uintptr_t)w & 15) == 0, "dwconv3x3_fwd_bn: c_real=%d of C=%d, w 16-byte aligned", c_real, C);
+  UH_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "dwconv3x3_fwd_bn: running stats must come in pairs");
+  const dim3 grid = dw_grid(B, H, W, C);
+  BnFwdFin fin{};
+  float* partial = nullptr;
+  UH_REQUIRE(fin_split((int)grid.x, C, 2, ws, ws_bytes, counters, fin.ws, partial),
+             "dwconv3x3_fwd_bn: workspace of %zu bytes (8-byte aligned) and counters needed", fin_ws_bytes((int)grid.x, C, 2));
+  fin.count = (double)B * H * W;
+  fin.gamma = gamma;
+  fin.beta = beta;
+  fin.eps = eps;
+  fin.momentum = momentum;
+  fin.mean = mean;
+  fin.invstd = invstd;
+  fin.scale = scale;
+  fin.shift = shift;
+  fin.rm = running_mean;
+  fin.rv = running_var;
+  fin.nbt = nbt;
+  fin.c_real = c_real;
+  const long long Mp = uh_mp(B, H, W);
+  const int rpi = ew_rows_per_iter(C);
+  hipLaunchKernelGGL(dwconv_fwd_kernel<UH_EPI_RAW_STATS>, grid, dim3(256), (size_t)rpi * 2 * C * 4, (hipStream_t)s, Mp, C,
+                     W + 1, (const char*)x, x_cstride, x_coff, w, c_real, bias, nullptr, nullptr, rowmask, (char*)out,
+                     o_cstride, o_coff, partial, fin);
+  return uh_check_launch("dwconv3x3_fwd_bn");
 }
 
 // ---- BatchNorm + residual + ReLU: a = relu(y*scale + shift + x) ---------------------------------------------------
@@ -252,7 +300,7 @@ __global__ __launch_bounds__(256) void bn_res_relu_bwd_reduce_kernel(
     long long Mp, int C, const char* __restrict__ da, int da_cs, int da_co, const char* __restrict__ y, int y_cs,
     int y_co, const char* __restrict__ x, int x_cs, int x_co, const float* __restrict__ mean,
     const float* __restrict__ invstd, const float* __restrict__ scale, const float* __restrict__ shift,
-    float* __restrict__ partial) {
+    float* __restrict__ partial, BnBwdFin fin) {
   extern __shared__ float lds[];
   const int cpr = C / 8, rpi = 256 / cpr;
   const int rr = threadIdx.x / cpr, cc = threadIdx.x % cpr;
@@ -281,7 +329,12 @@ __global__ __launch_bounds__(256) void bn_res_relu_bwd_reduce_kernel(
       }
     }
   }
-  block_combine_store<2>(acc, C, cpr, rpi, lds, partial + (long long)blockIdx.x * 2 * C);
+  if (fin.ws.counters) {
+    block_combine_store<2, true>(acc, C, cpr, rpi, lds, partial + (long long)blockIdx.x * 2 * C);
+    last_arriver_finish<2>(partial, C, fin.ws, fin);
+  } else {
+    block_combine_store<2>(acc, C, cpr, rpi, lds, partial + (long long)blockIdx.x * 2 * C);
+  }
 }
 
 extern "C" int uh_bn_res_relu_bwd_reduce(long long Mp, int C, const void* da, int da_cstride, int da_coff,
@@ -291,10 +344,41 @@ extern "C" int uh_bn_res_relu_bwd_reduce(long long Mp, int C, const void* da, in
   EW_CHECK("bn_res_relu_bwd_reduce", C);
   UH_REQUIRE(Mp > 0 && da && y && x && mean && invstd && scale && shift && partial, "bn_res_relu_bwd_reduce: bad arguments");
   const int rpi = ew_rows_per_iter(C);
+  BnBwdFin fin{};
   hipLaunchKernelGGL(bn_res_relu_bwd_reduce_kernel, dim3(ew_stat_blocks(Mp, C)), dim3(256), (size_t)rpi * 2 * C * 4,
                      (hipStream_t)s, Mp, C, (const char*)da, da_cstride, da_coff, (const char*)y, y_cstride, y_coff,
-                     (const char*)x, x_cstride, x_coff, mean, invstd, scale, shift, partial);
+                     (const char*)x, x_cstride, x_coff, mean, invstd, scale, shift, partial, fin);
   return uh_check_launch("bn_res_relu_bwd_reduce");
+}
+
+// the same launch followed, in its last workgroups, by what uh_bn_bwd_finalize does (ew.h: last_arriver_finish);
+// ws / counters: uh_fin_ws_bytes(uh_bn_bwd_parts(Mp, C), C, 2), uh_fin_counters()
+extern "C" int uh_bn_res_relu_bwd_reduce_fin(long long Mp, int C, const void* da, int da_cstride, int da_coff,
+                                             const void* y, int y_cstride, int y_coff, const void* x, int x_cstride,
+                                             int x_coff, const float* mean, const float* invstd, const float* scale,
+                                             const float* shift, int c_real, long long count, float* dgamma,
+                                             float* dbeta, float* coef, void* ws, size_t ws_bytes, unsigned* counters,
+                                             uh_stream s) {
+  EW_CHECK("bn_res_relu_bwd_reduce_fin", C);
+  UH_REQUIRE(Mp > 0 && da && y && x && mean && invstd && scale && shift && dgamma && dbeta && coef && count > 0 &&
+                 c_real > 0 && c_real <= C,
+             "bn_res_relu_bwd_reduce_fin: bad arguments");
+  const int parts = ew_stat_blocks(Mp, C);
+  BnBwdFin fin{};
+  float* partial = nullptr;
+  UH_REQUIRE(fin_split(parts, C, 2, ws, ws_bytes, counters, fin.ws, partial),
+             "bn_res_relu_bwd_reduce_fin: workspace of %zu bytes (8-byte aligned) and counters needed", fin_ws_bytes(parts, C, 2));
+  fin.count = (double)count;
+  fin.dgamma = dgamma;
+  fin.dbeta = dbeta;
+  fin.coef = coef;
+  fin.c_real = c_real;
+  fin.C = C;
+  const int rpi = ew_rows_per_iter(C);
+  hipLaunchKernelGGL(bn_res_relu_bwd_reduce_kernel, dim3(parts), dim3(256), (size_t)rpi * 2 * C * 4, (hipStream_t)s, Mp,
+                     C, (const char*)da, da_cstride, da_coff, (const char*)y, y_cstride, y_coff, (const char*)x,
+                     x_cstride, x_coff, mean, invstd, scale, shift, partial, fin);
+  return uh_check_launch("bn_res_relu_bwd_reduce_fin");
 }
 
 // dy = scale*(d - coef0 - xhat*coef1)  (gradient of the depthwise conv output),  dr = d  (residual branch)

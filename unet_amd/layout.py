@@ -75,6 +75,7 @@ class BufferPool:
         self.free = {}          # key -> list of tensors
         self.rowmasks = {}      # (B,H,W) -> uint8 tensor
         self.handed = {}        # id(tensor) -> times handed out (tells a reader that its buffer went to someone else)
+        self.fin_counters = {}  # stream handle -> zeroed int32 tensor
         self.bytes_allocated = 0
 
     def rowmask(self, B, H, W):
@@ -85,6 +86,14 @@ class BufferPool:
             _lib.call("uh_rowmask_build", B, H, W, m.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream)
             self.rowmasks[key] = m
         return m
+
+    def counters(self, stream):
+        """The arrival counters of the launches that finalise their own sums (uh_*_fin, uh_dwconv3x3_fwd_bn): one
+        zeroed array per stream handle; every such launch leaves it zero, and launches on one stream are ordered."""
+        c = self.fin_counters.get(stream)
+        if c is None:
+            c = self.fin_counters[stream] = torch.zeros(_lib_fn.uh_fin_counters(), dtype=torch.int32, device=self.device)
+        return c
 
     def lease(self):
         return Lease(self)

@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from . import _lib
 from ._lib import call, EPI_RAW_STATS, EPI_AFFINE_RELU, EPI_MASKED, EPI_CONVT
-from .engine import BN_EPS, BN_MOMENTUM, _stream, side_stream_for, ranged
+from .engine import BN_EPS, BN_MOMENTUM, _stream, side_stream_for, ranged, fused_finalize
 from .layout import pool_for
 from .packing import lunext_packer_for
 
@@ -126,16 +126,27 @@ class LUNeXtRun:
         rec.name, rec.x, rec.a, rec.C, rec.Cp, rec.lvl, rec.wt = name, x, a, C, Cp, lvl, wt
         rec.y = Ls.act(B, H, W, Cp)
         parts = L.uh_dw_parts(B, H, W, Cp)
-        stat = Ls.f32(parts * 2 * Cp)
-        call("uh_dwconv3x3_fwd", B, H, W, Cp, x.ptr, x.cstride, x.coff, wt.data_ptr(), C, bias.data_ptr(), EPI_RAW_STATS,
-             None, None, mask.data_ptr(), rec.y.ptr, rec.y.cstride, rec.y.coff, stat.data_ptr(), s)
         f = Ls.f32(4 * Cp)
         rec.mean, rec.invstd, rec.scale, rec.shift = f[:Cp], f[Cp:2 * Cp], f[2 * Cp:3 * Cp], f[3 * Cp:]
         # the C real channels of the parameters and running statistics are read and updated where they are
-        call("uh_bn_finalize", stat.data_ptr(), parts, Cp, C, B * H * W, blk.bn.weight.data_ptr(),
-             blk.bn.bias.data_ptr(), BN_EPS, BN_MOMENTUM, rec.mean.data_ptr(), rec.invstd.data_ptr(),
-             rec.scale.data_ptr(), rec.shift.data_ptr(), blk.bn.running_mean.data_ptr(),
-             blk.bn.running_var.data_ptr(), blk.bn.num_batches_tracked.data_ptr(), s)
+        if fused_finalize():
+            # the convolution's last workgroups also turn the batch statistics into scale / shift: no second launch
+            nbytes = L.uh_fin_ws_bytes(parts, Cp, 2)
+            ws = Ls.f32((nbytes + 3) // 4)
+            call("uh_dwconv3x3_fwd_bn", B, H, W, Cp, x.ptr, x.cstride, x.coff, wt.data_ptr(), C, bias.data_ptr(),
+                 mask.data_ptr(), rec.y.ptr, rec.y.cstride, rec.y.coff, blk.bn.weight.data_ptr(),
+                 blk.bn.bias.data_ptr(), BN_EPS, BN_MOMENTUM, rec.mean.data_ptr(), rec.invstd.data_ptr(),
+                 rec.scale.data_ptr(), rec.shift.data_ptr(), blk.bn.running_mean.data_ptr(),
+                 blk.bn.running_var.data_ptr(), blk.bn.num_batches_tracked.data_ptr(), ws.data_ptr(), nbytes,
+                 self.pool.counters(s).data_ptr(), s)
+        else:
+            stat = Ls.f32(parts * 2 * Cp)
+            call("uh_dwconv3x3_fwd", B, H, W, Cp, x.ptr, x.cstride, x.coff, wt.data_ptr(), C, bias.data_ptr(),
+                 EPI_RAW_STATS, None, None, mask.data_ptr(), rec.y.ptr, rec.y.cstride, rec.y.coff, stat.data_ptr(), s)
+            call("uh_bn_finalize", stat.data_ptr(), parts, Cp, C, B * H * W, blk.bn.weight.data_ptr(),
+                 blk.bn.bias.data_ptr(), BN_EPS, BN_MOMENTUM, rec.mean.data_ptr(), rec.invstd.data_ptr(),
+                 rec.scale.data_ptr(), rec.shift.data_ptr(), blk.bn.running_mean.data_ptr(),
+                 blk.bn.running_var.data_ptr(), blk.bn.num_batches_tracked.data_ptr(), s)
         call("uh_bn_res_relu_apply", x.Mp, Cp, rec.y.ptr, rec.y.cstride, rec.y.coff, x.ptr, x.cstride, x.coff,
              rec.scale.data_ptr(), rec.shift.data_ptr(), mask.data_ptr(), a.ptr, a.cstride, a.coff, s)
         self.recs[name] = rec
@@ -149,17 +160,24 @@ class LUNeXtRun:
         s, Ls = self._sh, self.lease
         mask = self.masks[rec.lvl]
         parts = L.uh_bn_bwd_parts(x.Mp, Cp)
-        partial = Ls.f32(parts * 2 * Cp)
         st = (rec.mean.data_ptr(), rec.invstd.data_ptr(), rec.scale.data_ptr(), rec.shift.data_ptr())
-        call("uh_bn_res_relu_bwd_reduce", x.Mp, Cp, da.ptr, da.cstride, da.coff, y.ptr, y.cstride, y.coff, x.ptr,
-             x.cstride, x.coff, *st, partial.data_ptr(), s)
         coef = Ls.f32(2 * Cp)
         if self.gflat is not None:
             dgam, dbet = self.gflat.views[name + ".bn.weight"], self.gflat.views[name + ".bn.bias"]
         else:
             dgam, dbet = torch.empty(2, C, dtype=torch.float32, device=self.device).unbind(0)
-        call("uh_bn_bwd_finalize", partial.data_ptr(), parts, Cp, C, B * H * W, dgam.data_ptr(), dbet.data_ptr(),
-             coef.data_ptr(), 0, s)                                          # the kernel writes the gradient tensors
+        if fused_finalize():                        # sums and their finalisation in one launch
+            nbytes = L.uh_fin_ws_bytes(parts, Cp, 2)
+            ws = Ls.f32((nbytes + 3) // 4)
+            call("uh_bn_res_relu_bwd_reduce_fin", x.Mp, Cp, da.ptr, da.cstride, da.coff, y.ptr, y.cstride, y.coff,
+                 x.ptr, x.cstride, x.coff, *st, C, B * H * W, dgam.data_ptr(), dbet.data_ptr(), coef.data_ptr(),
+                 ws.data_ptr(), nbytes, self.pool.counters(s).data_ptr(), s)
+        else:
+            partial = Ls.f32(parts * 2 * Cp)
+            call("uh_bn_res_relu_bwd_reduce", x.Mp, Cp, da.ptr, da.cstride, da.coff, y.ptr, y.cstride, y.coff, x.ptr,
+                 x.cstride, x.coff, *st, partial.data_ptr(), s)
+            call("uh_bn_bwd_finalize", partial.data_ptr(), parts, Cp, C, B * H * W, dgam.data_ptr(), dbet.data_ptr(),
+                 coef.data_ptr(), 0, s)                                      # the kernel writes the gradient tensors
         grads[name + ".bn.weight"], grads[name + ".bn.bias"] = dgam, dbet
         if FUSED_DW_BWD:
             wparts = L.uh_dwblock_bwd_parts(B, H, W, Cp)
