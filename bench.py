@@ -168,6 +168,34 @@ def lunext_result(args, with_cpu_baseline):
     return out
 
 
+def config3_per_gpu(dev, steps=8, warmup=3):
+    """The per-GPU workload of BASELINE configs[3] (UNet 3x512x512, batch 16 per GPU, data-parallel on 2/4/8 GPUs) on
+    this one GPU: forward + BCE + backward + Adam, no collective (a one-rank job has none)."""
+    import torch
+    import unet_amd
+    from unet_amd.dp import DataParallelTrainer
+    size, batch = 512, 16
+    torch.manual_seed(0)
+    model = unet_amd.UNet(3, 1).to(dev)
+    trainer = DataParallelTrainer(model, lr=1e-3, standalone=True)
+    x, m = synth_batch(batch, 3, size, size)
+    x, m = x.to(dev), m.to(dev)
+    for _ in range(warmup):
+        trainer.train_step(x, m)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = trainer.train_step(x, m)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    value = batch * steps / dt
+    return {"metric": "train imgs/sec on one GPU, UNet 512^2 bf16 fwd+bwd+Adam, batch 16 (the per-GPU workload of BASELINE "
+                      "configs[3])", "value": round(value, 2), "unit": "img/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(dt / steps * 1e3, 3), "dtype": "bf16", "data": "synthetic",
+            "step_mfma_frac": round(value * FLOP_PER_IMG_FWD_BWD * (size / IMG) ** 2 / PEAK_BF16_DENSE, 4),
+            "loss_last_step": round(loss.item(), 6)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -328,6 +356,8 @@ def main():
             del trainer, model
             torch.cuda.empty_cache()
             out["config2_lunext_cldice"] = lunext_result(args, not args.no_cpu_baseline)
+            torch.cuda.empty_cache()
+            out["config3_per_gpu"] = config3_per_gpu(dev)
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()
