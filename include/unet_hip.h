@@ -350,6 +350,12 @@ int uh_gate8_bwd(long long Mp, int c_real, const void* dout, int d_cstride, int 
                  const void* x, int x_cstride, int x_coff, const float* wts,
                  void* dg, int dg_cstride, int dg_coff, void* dx, int dx_cstride, int dx_coff,
                  float* partial, uh_stream s);
+/* the table uh_gate8_fwd / uh_gate8_bwd take, from the gate's three [C][C] weights and three biases where they lie
+ * (lunext.py:67-73), in one launch; and rows of `cin` floats zero-padded to rows of `cpad` (the head's [oc][cin] weight
+ * as [oc][8], a 3-channel bias as 8 channels) */
+int uh_gate8_pack(int c_real, const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                  const float* b3, float* wts216, uh_stream s);
+int uh_pad_rows_f32(int rows, int cin, int cpad, const float* src, float* dst, uh_stream s);
 /* NCHW fp32 image (Cin <= 8) -> 8-channel padded-linear bf16 */
 int uh_nchw_to_c8(int B, int Cin, int H, int W, const float* x, void* out, int o_cstride, int o_coff, uh_stream s);
 

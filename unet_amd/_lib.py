@@ -94,6 +94,8 @@ SIGNATURES = {
     "uh_gate8_bwd": (I, [L, I, P, I, I, P, I, I, P, I, I, P, P, I, I, P, I, I, P, P]),
     "uh_nchw_to_c8": (I, [I, I, I, I, P, P, I, I, P]),
     "uh_adam_step": (I, [L, P, P, P, P, F, F, F, F, F, I, P]),
+    "uh_gate8_pack": (I, [I, P, P, P, P, P, P, P, P]),
+    "uh_pad_rows_f32": (I, [I, I, I, P, P, P]),
     "uh_sigmoid_clamp": (I, [L, P, F, F, P, P]),
     "uh_sigmoid_clamp_bwd": (I, [L, P, F, F, P, P, P]),
     "uh_colsum_finalize_gather": (I, [P, I, I, I, P, P, P]),

@@ -1248,3 +1248,44 @@ extern "C" int uh_nchw_to_c8(int B, int Cin, int H, int W, const float* x, void*
                      (char*)out, o_cstride, o_coff);
   return uh_check_launch("nchw_to_c8");
 }
+
+// ---- small parameter tables for the 8-channel level, made on the device in one launch each -------------------------
+// uh_gate8_pack: the gate's three [C][C] 1x1 weights and three biases (lunext.py:67-73) -> the [3][8][8] | [3][8] table
+// uh_gate8_fwd / uh_gate8_bwd take, zero beyond the C real channels.  uh_pad_rows_f32: rows of `cin` floats -> rows of
+// `cpad` floats, zero-filled (the head's [oc][cin] weight as [oc][8], a 3-channel bias as 8 channels).
+__global__ void gate8_pack_kernel(int C, const float* w1, const float* b1, const float* w2, const float* b2,
+                                  const float* w3, const float* b3, float* __restrict__ out) {
+  const int i = threadIdx.x;
+  if (i >= 216) return;
+  const float* w[3] = {w1, w2, w3};
+  const float* b[3] = {b1, b2, b3};
+  float v = 0.f;
+  if (i < 192) {
+    const int j = i >> 6, r = (i >> 3) & 7, c = i & 7;
+    if (r < C && c < C) v = w[j][r * C + c];
+  } else {
+    const int j = (i - 192) >> 3, c = (i - 192) & 7;
+    if (c < C) v = b[j][c];
+  }
+  out[i] = v;
+}
+
+extern "C" int uh_gate8_pack(int c_real, const float* w1, const float* b1, const float* w2, const float* b2,
+                             const float* w3, const float* b3, float* wts216, uh_stream s) {
+  UH_REQUIRE(c_real >= 1 && c_real <= 8 && w1 && b1 && w2 && b2 && w3 && b3 && wts216, "gate8_pack: bad arguments");
+  hipLaunchKernelGGL(gate8_pack_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, c_real, w1, b1, w2, b2, w3, b3, wts216);
+  return uh_check_launch("gate8_pack");
+}
+
+__global__ void pad_rows_kernel(int rows, int cin, int cpad, const float* __restrict__ src, float* __restrict__ dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cpad) return;
+  const int r = i / cpad, c = i - r * cpad;
+  dst[i] = c < cin ? src[r * cin + c] : 0.f;
+}
+
+extern "C" int uh_pad_rows_f32(int rows, int cin, int cpad, const float* src, float* dst, uh_stream s) {
+  UH_REQUIRE(rows > 0 && cin > 0 && cpad >= cin && src && dst && (long long)rows * cpad < (1ll << 30), "pad_rows_f32: bad arguments");
+  hipLaunchKernelGGL(pad_rows_kernel, dim3((rows * cpad + 255) / 256), dim3(256), 0, (hipStream_t)s, rows, cin, cpad, src, dst);
+  return uh_check_launch("pad_rows_f32");
+}

@@ -270,7 +270,10 @@ class LUNeXtRun:
         wp = self.wf[f"up{k}"]
         B, H, W = self.geo[l]
         out = Ls.act(B, 2 * Hs, 2 * Ws, cpo)
-        bias = _padv(up.bias, cpo)
+        bias = up.bias.detach()
+        if cpo != cout:                                    # 3 real channels carried as 8
+            bias = Ls.f32(cpo)
+            call("uh_pad_rows_f32", 1, cout, cpo, up.bias.data_ptr(), bias.data_ptr(), s)
         call("uh_conv_gemm", Bs, Hs, Ws, x.ptr, x.cstride, x.coff, cin, wp.data_ptr(), N, 1, EPI_CONVT, out.ptr,
              out.cstride, out.coff, bias.data_ptr(), None, None, None, self.masks[l + 1].data_ptr(), s)
         self.saved[f"up{k}"] = (x, N)
@@ -383,10 +386,9 @@ class LUNeXtRun:
         out = Ls.act(B, H, W, Cp)
         if Cp == 8:
             wts = Ls.f32(216)
-            wts.zero_()
-            for j, conv in enumerate((att.sigmoid_conv, att.tanh_conv, att.combine_conv)):
-                wts[64 * j:64 * j + 64].view(8, 8)[:C, :C] = conv.weight.detach().view(C, C)
-                wts[192 + 8 * j:192 + 8 * j + C] = conv.bias.detach()
+            a1, a2, a3 = att.sigmoid_conv, att.tanh_conv, att.combine_conv
+            call("uh_gate8_pack", C, a1.weight.data_ptr(), a1.bias.data_ptr(), a2.weight.data_ptr(), a2.bias.data_ptr(),
+                 a3.weight.data_ptr(), a3.bias.data_ptr(), wts.data_ptr(), s)
             call("uh_gate8_fwd", g.Mp, C, g.ptr, g.cstride, g.coff, x.ptr, x.cstride, x.coff, wts.data_ptr(),
                  self.masks[l].data_ptr(), out.ptr, out.cstride, out.coff, s)
             self.saved[f"att{k}"] = (g, x, wts)
@@ -395,7 +397,11 @@ class LUNeXtRun:
         call("uh_add", g.Mp, C, g.ptr, g.cstride, g.coff, x.ptr, x.cstride, x.coff, None, 0, 0, ssum.ptr, ssum.cstride,
              ssum.coff, s)
         w12, w3 = self.wf[f"att{k}.w12"], self.wf[f"att{k}.w3"]
-        b12 = torch.cat([att.sigmoid_conv.bias.detach(), att.tanh_conv.bias.detach()])
+        b1, b2 = att.sigmoid_conv.bias.detach(), att.tanh_conv.bias.detach()
+        if b1.data_ptr() + 4 * C == b2.data_ptr():        # side by side (parameters living in a flat buffer laid out
+            b12 = b1                                      # by flat_param_order): read as one 2C vector where they are
+        else:
+            b12 = torch.cat([b1, b2])
         z = Ls.act(B, H, W, 3 * C)
         mask = self.masks[l]
         call("uh_conv_gemm", B, H, W, g.ptr, g.cstride, g.coff, C, w12.data_ptr(), 2 * C, 1, EPI_MASKED, z.ptr,
@@ -513,8 +519,8 @@ class LUNeXtRun:
             cur = self._dw(f"conv_up{k}_2", self._dw(f"conv_up{k}_1", cur, l), l)
         oc = m.out_channels
         fc = m.final_conv
-        w = torch.zeros(oc, 8, dtype=torch.float32, device=self.device)
-        w[:, :cin] = fc.weight.detach().view(oc, cin)
+        w = Ls.f32(oc * 8).view(oc, 8)
+        call("uh_pad_rows_f32", oc, cin, 8, fc.weight.data_ptr(), w.data_ptr(), s)
         logits = torch.empty(B, oc, H, W, dtype=torch.float32, device=self.device)
         call("uh_head_fwd", B, H, W, 8, oc, cur.ptr, cur.cstride, cur.coff, w.data_ptr(), fc.bias.data_ptr(),
              logits.data_ptr(), s)
