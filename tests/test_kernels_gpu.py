@@ -774,8 +774,8 @@ def test_batchnorm_relu_apply_with_pooling(B, H, W, C):
 
 
 @pytest.mark.parametrize("B,H,W,C,c_real", [(2, 16, 16, 64, 64), (1, 20, 12, 8, 3), (2, 5, 7, 128, 128), (1, 33, 4, 256, 256),
-                                            (1, 3, 3, 512, 512)])
-def test_depthwise_block_backward_in_one_pass(B, H, W, C, c_real):
+                                            (1, 3, 3, 512, 512), (2, 40, 30, 64, 64), (3, 37, 45, 16, 16)])
+def test_depthwise_block_backward_in_one_pass(B, H, W, C, c_real, monkeypatch):
     """uh_dwblock_bwd against the three passes it replaces (uh_bn_res_relu_bwd_apply, uh_dwconv3x3_dgrad,
     uh_dwconv3x3_wgrad): the same gradients up to the bf16 rounding of dy that the fused pass does not make."""
     g = torch.Generator().manual_seed(73)
@@ -811,7 +811,20 @@ def test_depthwise_block_backward_in_one_pass(B, H, W, C, c_real):
     dw0, dw1 = torch.empty(c_real, 1, 3, 3, device=DEV), torch.empty(c_real, 1, 3, 3, device=DEV)
     call("uh_dw_wgrad_finalize", wp0.data_ptr(), p0, C, c_real, dw0.data_ptr(), S())
     call("uh_dw_wgrad_finalize", wp1.data_ptr(), p1, C, c_real, dw1.data_ptr(), S())
+    # the workgroup kernel with the LDS exchange (UNET_AMD_DWBLOCK_LDS=1): dx bit for bit, dw up to summation order
+    monkeypatch.setenv("UNET_AMD_DWBLOCK_LDS", "1")
+    p2 = lib.uh_dwblock_bwd_parts(B, H, W, C)
+    wp2 = torch.full((p2, 9, C), float("nan"), device=DEV)
+    dx2 = new_act(B, H, W, C, DEV)
+    call("uh_dwblock_bwd", B, H, W, C, daa.ptr, daa.cstride, daa.coff, ya.ptr, ya.cstride, ya.coff, xa.ptr, xa.cstride,
+         xa.coff, wt.data_ptr(), c_real, *stp, coef.data_ptr(), dx2.ptr, dx2.cstride, dx2.coff,
+         wp2.data_ptr(), S())
+    monkeypatch.delenv("UNET_AMD_DWBLOCK_LDS")
+    dw2 = torch.empty(c_real, 1, 3, 3, device=DEV)
+    call("uh_dw_wgrad_finalize", wp2.data_ptr(), p2, C, c_real, dw2.data_ptr(), S())
     torch.cuda.synchronize()
+    assert torch.equal(dx1.to_nchw(), dx2.to_nchw()), "strip walk and workgroup kernel disagree on dx"
+    close(dw1, dw2, 1e-4, "dw, strip walk against workgroup kernel")
     pads_are_zero(dx1)
     close(dx1.to_nchw(), dx0.to_nchw(), 1.2e-2, "dx")           # nine products of values rounded at 2^-9, then summed
     assert torch.isfinite(dw1).all()

@@ -7,6 +7,8 @@
 // stencil (forward, input gradient, weight gradient), BatchNorm+residual+ReLU and its backward, the gate's
 // pointwise parts, and the fully fused 8-channel gate of the top level.
 #include "ew.h"
+#include <cstdlib>
+#include <type_traits>
 
 // ---- depthwise 3x3, pad 1 ------------------------------------------------------------------------------------
 // The padded-linear tensor is one long grid of B*(H+1) rows of Wp = W+1 positions whose pad positions are zero, so a
@@ -732,12 +734,15 @@ __global__ __launch_bounds__(256) void dwblock_bwd_kernel(
     float o[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      float v = dm[j];
+      // summation order of dx: the row above, the centre term, this row, the row below (the order in which a walk
+      // that meets each row once can add them; dwblock_bwd_strip_kernel does, and gives the same bits)
+      float v = 0.f;
 #pragma unroll
       for (int d = 0; d < 3; ++d) {
-        v = fmaf(bot[2 - d][j], w[d][j], v);
-        acc[d][j] = fmaf(xm[j], bot[2 - d][j], acc[d][j]);
+        v = fmaf(top[2 - d][j], w[6 + d][j], v);
+        acc[6 + d][j] = fmaf(xm[j], top[2 - d][j], acc[6 + d][j]);
       }
+      v += dm[j];
 #pragma unroll
       for (int d = 0; d < 3; ++d) {
         v = fmaf(mid[2 - d][j], w[3 + d][j], v);
@@ -745,8 +750,8 @@ __global__ __launch_bounds__(256) void dwblock_bwd_kernel(
       }
 #pragma unroll
       for (int d = 0; d < 3; ++d) {
-        v = fmaf(top[2 - d][j], w[6 + d][j], v);
-        acc[6 + d][j] = fmaf(xm[j], top[2 - d][j], acc[6 + d][j]);
+        v = fmaf(bot[2 - d][j], w[d][j], v);
+        acc[d][j] = fmaf(xm[j], bot[2 - d][j], acc[d][j]);
       }
       o[j] = okc[(r + 1) % 3] ? v : 0.f;             // (the window around a pad position holds real neighbours)
     }
@@ -774,8 +779,279 @@ __global__ __launch_bounds__(256) void dwblock_bwd_kernel(
   }
 }
 
+// ---- the same pass as a strip walk without LDS memory or barriers ----------------------------------------------------
+// dwblock_bwd_kernel above exchanges dy between the columns of a workgroup through LDS, with a barrier per row, and
+// holds a 3x3 window per thread (~220 registers): two workgroups per CU that wait for each other sixteen times per
+// strip.  Here a WAVE owns 16 adjacent columns (14 core columns + one halo column on either side) of four
+// (column block, channel group) pairs, four channels per lane, and the neighbouring columns come from other lanes of
+// the wave through ds_bpermute (the LDS crossbar; no LDS memory), so waves never wait for one another.  The pair index
+// is the FASTEST lane index (lane = 4 * column + pair): where the pairs are adjacent channel groups of one column
+// block, four adjacent lanes read 32 contiguous bytes, which the texture unit merges into one access -- with the
+// column fastest every lane is an access of its own and the L1 tag rate, not HBM, bounds the kernel (measured: 64
+// accesses per load instruction, 47 M per launch at 64 channels, 128 x 128, batch 32).
+// Each tensor row is met ONCE, when it arrives: its dy values finish the output row above (its bottom taps), extend
+// the output row itself (centre term, middle taps) and start the output row below (top taps), so no window is kept,
+// only two partial output rows.  The weight gradient pairs a dy row with the block input of the rows above, at and
+// below it, which is why it runs one row behind the arrivals.  The four pairs of a wave belong to ONE strip: row
+// counters, the image-row test and the address steps are then wave-uniform and run on the scalar unit.  Per-lane
+// arithmetic and its order are those of dwblock_bwd_kernel: dx is bit-identical; the weight-gradient partial rows are
+// one per (strip, column block) instead of one per workgroup.
+#define DWS_CORE 14
+#define DWS_PF 3      // a row's loads are issued this many steps before its use
+__device__ __forceinline__ float lane_read(int byte_addr, float v) {          // v of lane byte_addr / 4
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_addr, __builtin_bit_cast(int, v)));
+}
+
+struct DwsGeo {
+  long long strips, waves;
+  int nsx, ncg, wps, R;     // column blocks, channel groups, waves per strip, output rows per strip
+};
+static inline DwsGeo dws_geo_r(int B, int H, int W, int C, int R) {
+  DwsGeo g;
+  g.R = R;
+  g.strips = ((long long)B * (H + 1) + R - 1) / R;
+  g.nsx = (W + 1 + DWS_CORE - 1) / DWS_CORE;
+  g.ncg = C / 4;
+  g.wps = (g.nsx * g.ncg + 3) / 4;
+  g.waves = g.strips * g.wps;
+  return g;
+}
+// Strips of 18 rows: 21 rows are read for 18.  (Strips of 9 rows double the number of waves at the small levels and
+// were measured slower there, 33.9 against 27.2 us at 256 channels, 32 x 32, batch 32: a wave's fixed cost outweighs
+// the shorter walk.)
+#define DWS_R 18
+static inline DwsGeo dws_geo(int B, int H, int W, int C) { return dws_geo_r(B, H, W, C, DWS_R); }
+
+template <int R>
+__global__ __launch_bounds__(256) void dwblock_bwd_strip_kernel(
+    long long Mp, int C, int Wp, int Hp, long long waves, int nsx, int wps, const char* __restrict__ da, int da_cs,
+    int da_co, const char* __restrict__ y, int y_cs, int y_co, const char* __restrict__ x, int x_cs, int x_co,
+    const float* __restrict__ wt, int c_real, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ coef,
+    char* __restrict__ dx, int dx_cs, int dx_co, float* __restrict__ partial) {
+  const int ncg = C / 4;
+  const int lane = threadIdx.x & 63;
+  const int xi = lane >> 2;
+  // workgroups go to the eight XCDs in turn: each XCD gets a contiguous range of strips, so the halo rows and columns
+  // that neighbouring waves share are found in its own L2 (the grid is a multiple of 8)
+  const long long blk = (long long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const long long wv = blk * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (wv >= waves) return;                                    // whole waves leave; nothing below waits for another wave
+  const long long strip = wv / wps;
+  const int q = (int)(wv % wps) * 4 + (lane & 3);
+  const int left_lane = (lane - 4) * 4, right_lane = (lane + 4) * 4;          // byte addresses for ds_bpermute
+  const bool live = q < nsx * ncg;
+  const int qc = live ? q : 0;
+  const int cg = qc % ncg, sx = qc / ncg;
+  const int c0 = cg * 4;
+  const long long rows = Mp / Wp;
+  const long long r0 = strip * R;
+  const int xcol = sx * DWS_CORE - 1 + xi;                    // this lane's column; -1 and >= Wp - 1 are never interior
+  const bool core = live & (xi >= 1) & (xi <= DWS_CORE) & (xcol < Wp);  // columns this lane writes (pad column included)
+  const bool col_in = live & (xcol >= 0) & (xcol < Wp - 1);   // an interior column of the images
+  float acc[9][4], w[9][4], sc[4], sh[4], bp[4], cq[4];
+  // step e (0 .. R + 2) meets tensor row r0 - 1 + e.  The row before the first strip is a guard row (zeros, and
+  // counts as a pad row); past the last row the walk stays on the first row after the end (a guard row as well) and
+  // everything there counts as padding.  All of this is the same for the whole wave.
+  const long long left_ll = rows - r0;
+  const int left = (int)(left_ll < (1 << 20) ? left_ll : (1 << 20));       // rows from r0 to the end of the tensor
+  const int nr = left < R ? left : R;
+  const long long m0 = (r0 - 1) * Wp + xcol;
+  const char* dap = da + (m0 * da_cs + da_co + c0) * 2;
+  const char* yp = y + (m0 * y_cs + y_co + c0) * 2;
+  const char* xp = x + (m0 * x_cs + x_co + c0) * 2;
+  const long long da_row = (long long)da_cs * 2 * Wp, y_row = (long long)y_cs * 2 * Wp, x_row = (long long)x_cs * 2 * Wp;
+  int ry_f = (int)((r0 + Hp - 1) % Hp);                       // image row of the row the next fetch reads
+  int ry_u = ry_f;                                            // ... and of the row the next step uses
+  auto fetch = [&](int e, DwbRaw& t) {
+    t.g = *(const U2*)dap;
+    t.v = *(const U2*)yp;
+    t.r = *(const U2*)xp;
+    const bool in = e <= left;
+    dap += in ? da_row : 0;
+    yp += in ? y_row : 0;
+    xp += in ? x_row : 0;
+  };
+  auto eval = [&](const DwbRaw& t, bool keep, float (&dyv)[4], float (&dc)[4], float (&xc)[4]) {
+    float gf[4], vf[4], xf[4];
+    unpack4(t.g, gf);
+    unpack4h(t.v, vf);
+    unpack4(t.r, xf);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool on = keep & (vf[j] * sc[j] + sh[j] + xf[j] > 0.f);
+      const float d = on ? gf[j] : 0.f;
+      dc[j] = d;
+      xc[j] = keep ? xf[j] : 0.f;
+      const float qv = fmaf(sc[j], d, -fmaf(vf[j], cq[j], bp[j]));
+      dyv[j] = keep ? qv : 0.f;
+    }
+  };
+  DwbRaw raw[DWS_PF];
+#pragma unroll
+  for (int e = 0; e < DWS_PF; ++e) fetch(e, raw[e]);
+  // (the rows' first loads are on their way while the parameters are read)
+  if (c0 + 4 <= c_real) {                                     // 36 consecutive floats: nine 16-byte loads
+    const float4* wp4 = (const float4*)(wt + c0 * 9);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const float4 v4 = wp4[i];
+      const float f[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) w[(i * 4 + k) % 9][(i * 4 + k) / 9] = f[k];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int c = c0 + j;
+        const float wv9 = wt[(c < c_real ? c : c_real - 1) * 9 + t];
+        w[t][j] = (c < c_real) ? wv9 : 0.f;
+      }
+  }
+  {
+    const float4 s4 = *(const float4*)(scale + c0), h4 = *(const float4*)(shift + c0), i4 = *(const float4*)(invstd + c0),
+                 m4 = *(const float4*)(mean + c0), a4 = *(const float4*)(coef + c0), b4 = *(const float4*)(coef + C + c0);
+    const float s_[4] = {s4.x, s4.y, s4.z, s4.w}, h_[4] = {h4.x, h4.y, h4.z, h4.w}, i_[4] = {i4.x, i4.y, i4.z, i4.w},
+                m_[4] = {m4.x, m4.y, m4.z, m4.w}, a_[4] = {a4.x, a4.y, a4.z, a4.w}, b_[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      sc[j] = s_[j];
+      sh[j] = h_[j];
+      cq[j] = sc[j] * b_[j] * i_[j];
+      bp[j] = sc[j] * a_[j] - cq[j] * m_[j];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc[t][j] = 0.f;
+    }
+  }
+  float xr[3][4];                                             // block input of the rows of steps e - 2, e - 1, e (mod 3)
+  float part_a[4], part_b[4];                                 // output rows e - 2 (top and middle taps in) and e - 1 (top taps in)
+  float hc[4], hd[4], hl[4], hr[4];                           // row of step e - 1: dy and centre term at this column, dy left, dy right
+  bool ok_a = false, ok_h = false;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    xr[0][j] = xr[1][j] = xr[2][j] = 0.f;
+    part_a[j] = part_b[j] = hc[j] = hd[j] = hl[j] = hr[j] = 0.f;
+  }
+  char* op = dx + (((r0 - 3) * Wp + xcol) * dx_cs + dx_co + c0) * 2;         // step e finishes the row of step e - 2
+  const long long orow = (long long)dx_cs * 2 * Wp;
+  // Step e has two halves.  The first evaluates the row that arrives (step e's) and sends its dy to the neighbouring
+  // lanes; the second works on the row of step e - 1, whose exchanged values have had a whole step to come back:
+  // bottom taps finish output row e - 2, centre term and middle taps extend row e - 1, top taps start row e, and the
+  // weight gradient pairs it with the block input of rows e - 2, e - 1 and e.  Rows that do not exist (before step 0,
+  // after step R + 1) are rows of zeros.
+  auto step = [&](auto ph, auto with_fetch, int e) {
+    constexpr int S0 = decltype(ph)::value;                   // e mod 3
+    constexpr int S1 = (S0 + 2) % 3, S2 = (S0 + 1) % 3;       // slots of steps e - 1 and e - 2
+    const bool row_ok = (e <= left) & (ry_u != Hp - 1) & (e <= R + 1);
+    ry_u = ry_u + 1 == Hp ? 0 : ry_u + 1;
+    const bool ok = row_ok & col_in;
+    float c[4], dc[4], xc[4], nl[4], nr4[4];
+    eval(raw[S0], ok, c, dc, xc);
+    if constexpr (decltype(with_fetch)::value) fetch(e + DWS_PF, raw[S0]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      nl[j] = lane_read(left_lane, c[j]);                     // (the first and last column of the wave read some other
+      nr4[j] = lane_read(right_lane, c[j]);                   //  lane: their taps are incomplete anyway, see `core`)
+    }
+    const bool own_row = (e >= 1) & (e <= R);             // only the strip's own rows add their block input
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xr[S0][j] = (core & own_row) ? xc[j] : 0.f;
+    // ---- second half: the row of step e - 1 (tap d of a row pairs with the column x + 1 - d)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[0][j] = fmaf(xr[S2][j], hr[j], acc[0][j]);
+      acc[1][j] = fmaf(xr[S2][j], hc[j], acc[1][j]);
+      acc[2][j] = fmaf(xr[S2][j], hl[j], acc[2][j]);
+      acc[3][j] = fmaf(xr[S1][j], hr[j], acc[3][j]);
+      acc[4][j] = fmaf(xr[S1][j], hc[j], acc[4][j]);
+      acc[5][j] = fmaf(xr[S1][j], hl[j], acc[5][j]);
+      acc[6][j] = fmaf(xr[S0][j], hr[j], acc[6][j]);
+      acc[7][j] = fmaf(xr[S0][j], hc[j], acc[7][j]);
+      acc[8][j] = fmaf(xr[S0][j], hl[j], acc[8][j]);
+    }
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v = part_a[j];                                    // the bottom taps finish output row e - 2
+      v = fmaf(hr[j], w[0][j], v);
+      v = fmaf(hc[j], w[1][j], v);
+      v = fmaf(hl[j], w[2][j], v);
+      o[j] = ok_a ? v : 0.f;                                  // (the window around a pad position holds real neighbours)
+      v = part_b[j] + hd[j];                                  // centre term and middle taps: output row e - 1
+      v = fmaf(hr[j], w[3][j], v);
+      v = fmaf(hc[j], w[4][j], v);
+      part_a[j] = fmaf(hl[j], w[5][j], v);
+      float t = fmaf(hr[j], w[6][j], 0.f);                    // top taps: output row e starts
+      t = fmaf(hc[j], w[7][j], t);
+      part_b[j] = fmaf(hl[j], w[8][j], t);
+    }
+    if (core & (e >= 3) & (e - 2 <= nr)) {
+      U2 ov;
+      ov.x = pack2(o[0], o[1]);
+      ov.y = pack2(o[2], o[3]);
+      *(U2*)op = ov;
+    }
+    op += orow;
+    ok_a = ok_h;
+    ok_h = ok;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      hc[j] = c[j];
+      hd[j] = dc[j];
+      hl[j] = nl[j];
+      hr[j] = nr4[j];
+    }
+  };
+  static_assert(R % 3 == 0 && DWS_PF == 3, "the rings are walked three steps at a time");
+  using Yes = std::true_type;
+  using No = std::false_type;
+  // (the last loop pass fetches the row of step R + 2, which nothing uses: one row in R + 2 that the next strip
+  //  reads anyway, for a loop body without a condition)
+#pragma unroll 1
+  for (int e = 0; e < R; e += 3) {
+    step(std::integral_constant<int, 0>{}, Yes{}, e);
+    step(std::integral_constant<int, 1>{}, Yes{}, e + 1);
+    step(std::integral_constant<int, 2>{}, Yes{}, e + 2);
+  }
+  step(std::integral_constant<int, 0>{}, No{}, R);
+  step(std::integral_constant<int, 1>{}, No{}, R + 1);
+  step(std::integral_constant<int, 2>{}, No{}, R + 2);
+  // the 16 columns of a pair add their weight-gradient sums (halo lanes hold zeros) in a fixed order: lanes 0..3 end
+  // up with the totals of the four pairs
+  float* prow = partial + ((strip * nsx + sx) * 9) * C + c0;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v = acc[t][j];
+#pragma unroll
+      for (int sh8 = 32; sh8 >= 4; sh8 >>= 1) {
+        const float o = lane_read((lane + sh8) * 4, v);
+        v += (lane + sh8 < 64) ? o : 0.f;
+      }
+      acc[t][j] = v;
+    }
+  if (live & (xi == 0)) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) *(float4*)(prow + t * C) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+  }
+}
+
+// UNET_AMD_DWBLOCK_LDS=1: the workgroup kernel with the LDS exchange instead of the strip walk.  Read at every call
+// (uh_dwblock_bwd_parts and the launch that follows it see the same value), so a test can compare the two in one process.
+static bool dwb_use_strip() {
+  const char* e = getenv("UNET_AMD_DWBLOCK_LDS");
+  return !e || atoi(e) == 0;
+}
+
 extern "C" int uh_dwblock_bwd_parts(int B, int H, int W, int C) {
   if (!(B > 0 && H > 0 && W > 0 && C >= 8 && C <= 512 && (C & (C - 1)) == 0)) return 0;
+  if (dwb_use_strip()) {
+    const DwsGeo g = dws_geo(B, H, W, C);
+    return (int)(g.strips * g.nsx);
+  }
   return (int)dwb_grid(B, H, W, C).x;
 }
 
@@ -791,6 +1067,16 @@ extern "C" int uh_dwblock_bwd(int B, int H, int W, int C, const void* da, int da
   UH_REQUIRE(da_cstride % 4 == 0 && da_coff % 4 == 0 && y_cstride % 4 == 0 && y_coff % 4 == 0 && x_cstride % 4 == 0 &&
                  x_coff % 4 == 0 && dx_cstride % 4 == 0 && dx_coff % 4 == 0, "dwblock_bwd: bad views");
   const long long Mp = uh_mp(B, H, W);
+  if (dwb_use_strip()) {
+    const DwsGeo g = dws_geo(B, H, W, C);
+    UH_REQUIRE(g.strips * g.nsx < (1ll << 31) && (g.waves + 3) / 4 + 8 < (1ll << 31), "dwblock_bwd: %lld waves", g.waves);
+    auto* kern = dwblock_bwd_strip_kernel<DWS_R>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(((g.waves + 3) / 4 + 7) / 8 * 8)), dim3(256), 0, (hipStream_t)s, Mp, C,
+                       W + 1, H + 1, g.waves, g.nsx, g.wps, (const char*)da, da_cstride, da_coff, (const char*)y, y_cstride,
+                       y_coff, (const char*)x, x_cstride, x_coff, w, c_real, mean, invstd, scale, shift, coef, (char*)dx,
+                       dx_cstride, dx_coff, partial);
+    return uh_check_launch("dwblock_bwd");
+  }
   const int xt = 256 / (C / 4);
   hipLaunchKernelGGL(dwblock_bwd_kernel, dwb_grid(B, H, W, C), dim3(256), (size_t)xt * 9 * C * 4, (hipStream_t)s, Mp, C,
                      W + 1, H + 1, (const char*)da, da_cstride, da_coff, (const char*)y, y_cstride, y_coff,
