@@ -332,6 +332,22 @@ int uh_dwblock_bwd(int B, int H, int W, int C, const void* da, int da_cstride, i
                    const float* w, int c_real,
                    const float* mean, const float* invstd, const float* scale, const float* shift, const float* coef,
                    void* dx, int dx_cstride, int dx_coff, float* partial, uh_stream s);
+/* uh_dwblock_bwd for the second block of a pair (lunext.py:187-259 chains DepthwiseConvBlocks two by two: the second
+ * block's input x is the first block's output relu(bn(yq) + its input), read by nothing else, and dx is the first
+ * block's upstream gradient).  Also writes the FIRST block's BatchNorm-backward partial sums -- what
+ * uh_bn_res_relu_bwd_reduce would make of dx, yq and the first block's input -- to
+ * prev_partial[uh_dwblock_bwd_parts][2][C] for uh_bn_bwd_finalize, from the dx values as stored, the sign of x and one
+ * more tensor read, so that block needs no reduce pass of its own.  mean_q / invstd_q: the first block's batch
+ * statistics.  uh_dwblock_bwd_takes_prev() is 1 when the kernel in use can do this (0 under
+ * UNET_AMD_DWBLOCK_LDS=1, and uh_dwblock_bwd_prev then returns an error). */
+int uh_dwblock_bwd_takes_prev(void);
+int uh_dwblock_bwd_prev(int B, int H, int W, int C, const void* da, int da_cstride, int da_coff,
+                        const void* y, int y_cstride, int y_coff, const void* x, int x_cstride, int x_coff,
+                        const float* w, int c_real,
+                        const float* mean, const float* invstd, const float* scale, const float* shift, const float* coef,
+                        void* dx, int dx_cstride, int dx_coff, float* partial,
+                        const void* yq, int yq_cstride, int yq_coff, const float* mean_q, const float* invstd_q,
+                        float* prev_partial, uh_stream s);
 
 /* F.interpolate(x, size=(Ho, Wo), mode='bilinear', align_corners=False) and its backward (lunext.py:226-251: the
  * size fix after a transposed convolution when the skip connection is one row / column larger), padded-linear NHWC

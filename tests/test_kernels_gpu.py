@@ -841,6 +841,67 @@ def test_depthwise_block_backward_in_one_pass(B, H, W, C, c_real, monkeypatch):
     close(dw1, wr.grad, 2e-3, "dw against autograd")
 
 
+@pytest.mark.parametrize("B,H,W,C,c_real", [(2, 16, 16, 64, 64), (1, 20, 12, 8, 3), (2, 40, 30, 64, 64), (3, 37, 45, 16, 16),
+                                            (1, 3, 3, 512, 512)])
+def test_depthwise_block_backward_leaves_the_previous_block_its_sums(B, H, W, C, c_real):
+    """uh_dwblock_bwd_prev: same dx and weight-gradient partials as uh_dwblock_bwd, bit for bit, plus the
+    BatchNorm-backward sums of the block that produced x -- against uh_bn_res_relu_bwd_reduce on the stored dx."""
+    assert lib.uh_dwblock_bwd_takes_prev() == 1
+    g = torch.Generator().manual_seed(79)
+    live = (torch.arange(C) < c_real).float().view(1, C, 1, 1)
+    rnd = lambda: bf(torch.randn(B, C, H, W, generator=g)) * live                # noqa: E731
+    stats = lambda: [((t * live.view(-1)) if i >= 2 else t).to(DEV) for i, t in enumerate(        # noqa: E731
+        (torch.randn(C, generator=g) * 0.2, torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g),
+         torch.randn(C, generator=g) * 0.3))]
+    # the previous block: x = relu(scale_q * yq + shift_q + xin), made by the forward kernel itself
+    xin, yq = act_from(rnd()), act_from((torch.randn(B, C, H, W, generator=g) * 1.5).half().float() * live, half=True)
+    stq = stats()
+    mask = rowmask(B, H, W)
+    xa = new_act(B, H, W, C, DEV)
+    call("uh_bn_res_relu_apply", xa.Mp, C, yq.ptr, yq.cstride, yq.coff, xin.ptr, xin.cstride, xin.coff, stq[2].data_ptr(),
+         stq[3].data_ptr(), mask.data_ptr(), xa.ptr, xa.cstride, xa.coff, S())
+    # this block
+    daa = act_from(rnd())
+    ya = act_from((torch.randn(B, C, H, W, generator=g) * 1.5 + 0.2).half().float() * live, half=True)
+    wt = (torch.randn(c_real, 1, 3, 3, generator=g) / 3).to(DEV)
+    st = stats()
+    stp = [t.data_ptr() for t in st]
+    coef = (torch.randn(2, C, generator=g) * 0.05).to(DEV)
+    parts = lib.uh_dwblock_bwd_parts(B, H, W, C)
+    dx0, dx1 = new_act(B, H, W, C, DEV), new_act(B, H, W, C, DEV)
+    wp0, wp1 = torch.empty(parts, 9, C, device=DEV), torch.empty(parts, 9, C, device=DEV)
+    qp = torch.full((parts, 2, C), float("nan"), device=DEV)
+    call("uh_dwblock_bwd", B, H, W, C, daa.ptr, daa.cstride, daa.coff, ya.ptr, ya.cstride, ya.coff, xa.ptr, xa.cstride,
+         xa.coff, wt.data_ptr(), c_real, *stp, coef.data_ptr(), dx0.ptr, dx0.cstride, dx0.coff, wp0.data_ptr(), S())
+    call("uh_dwblock_bwd_prev", B, H, W, C, daa.ptr, daa.cstride, daa.coff, ya.ptr, ya.cstride, ya.coff, xa.ptr,
+         xa.cstride, xa.coff, wt.data_ptr(), c_real, *stp, coef.data_ptr(), dx1.ptr, dx1.cstride, dx1.coff,
+         wp1.data_ptr(), yq.ptr, yq.cstride, yq.coff, stq[0].data_ptr(), stq[1].data_ptr(), qp.data_ptr(), S())
+    # the separate pass over (dx, yq, xin)
+    rparts = lib.uh_bn_bwd_parts(xa.Mp, C)
+    rp = torch.empty(rparts, 2, C, device=DEV)
+    call("uh_bn_res_relu_bwd_reduce", xa.Mp, C, dx0.ptr, dx0.cstride, dx0.coff, yq.ptr, yq.cstride, yq.coff, xin.ptr,
+         xin.cstride, xin.coff, *[t.data_ptr() for t in stq], rp.data_ptr(), S())
+    outs = []
+    for part, n in ((rp, rparts), (qp, parts)):
+        dgam, dbet = torch.empty(c_real, device=DEV), torch.empty(c_real, device=DEV)
+        cf = torch.empty(2, C, device=DEV)
+        call("uh_bn_bwd_finalize", part.data_ptr(), n, C, c_real, B * H * W, dgam.data_ptr(), dbet.data_ptr(),
+             cf.data_ptr(), 0, S())
+        outs.append((dgam, dbet, cf))
+    torch.cuda.synchronize()
+    assert torch.equal(dx0.buf, dx1.buf) and torch.equal(wp0, wp1)
+    assert torch.isfinite(qp).all()
+    # scale of the sums: sum |d| and sum |d * xhat| per channel
+    d = dx0.to_nchw().float() * (xa.to_nchw() > 0)
+    xhat = (yq.to_nchw(half=True).float() - stq[0].view(1, -1, 1, 1)) * stq[1].view(1, -1, 1, 1)
+    mag0 = d.abs().sum((0, 2, 3))[:c_real] + 1e-6
+    mag1 = (d * xhat).abs().sum((0, 2, 3))[:c_real] + 1e-6
+    (g0, b0, c0), (g1, b1, c1) = outs
+    assert ((b1 - b0).abs() <= 2e-5 * mag0).all(), "dbeta"
+    assert ((g1 - g0).abs() <= 2e-5 * mag1).all(), "dgamma"
+    assert ((c1 - c0)[:, :c_real].abs() <= 2e-5 * torch.stack([mag0, mag1]) / (B * H * W) + 1e-9).all(), "coef"
+
+
 @pytest.mark.parametrize("B,H,W,C,OC", [(2, 8, 12, 64, 1), (1, 5, 7, 64, 2), (2, 16, 16, 8, 1)])
 def test_head_backward_with_batchnorm_backward_sums(B, H, W, C, OC):
     """uh_head_bwd_bnstat: gradient and weight partials as uh_head_bwd, bit for bit; sums as the separate pass."""

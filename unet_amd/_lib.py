@@ -86,6 +86,8 @@ SIGNATURES = {
     "uh_resize_bilinear_bwd": (I, [I, I, I, I, I, I, P, I, I, P, I, I, P]),
     "uh_dwblock_bwd_parts": (I, [I, I, I, I]),
     "uh_dwblock_bwd": (I, [I, I, I, I, P, I, I, P, I, I, P, I, I, P, I, P, P, P, P, P, P, I, I, P, P]),
+    "uh_dwblock_bwd_takes_prev": (I, []),
+    "uh_dwblock_bwd_prev": (I, [I, I, I, I, P, I, I, P, I, I, P, I, I, P, I, P, P, P, P, P, P, I, I, P, P, I, I, P, P, P, P]),
     "uh_gate_fwd": (I, [L, I, P, I, I, P, I, I, P, I, I, P]),
     "uh_gate_bwd": (I, [L, I, P, I, I, P, I, I, P, I, I, P, P, I, I, P, I, I, P]),
     "uh_add": (I, [L, I, P, I, I, P, I, I, P, I, I, P, I, I, P]),

@@ -822,13 +822,24 @@ static inline DwsGeo dws_geo_r(int B, int H, int W, int C, int R) {
 #define DWS_R 18
 static inline DwsGeo dws_geo(int B, int H, int W, int C) { return dws_geo_r(B, H, W, C, DWS_R); }
 
-template <int R>
+// PREV: the block's input x is the output of another depthwise block (x = relu(bn(yq) + its input)) and dx is that
+// block's upstream gradient.  Its BatchNorm-backward sums (sum d, sum d * xhat with d = dx where x > 0, what
+// bn_res_relu_bwd_reduce_kernel makes from dx, yq and its input) are then taken here, from the dx values as they are
+// stored and one more tensor read (yq), instead of a pass of their own over three tensors.
+struct DwsPrev {
+  const char* yq;
+  int cs, co;
+  const float *mean, *invstd;
+  float* partial;       // [strips * column blocks][2][C]
+};
+
+template <int R, bool PREV>
 __global__ __launch_bounds__(256) void dwblock_bwd_strip_kernel(
     long long Mp, int C, int Wp, int Hp, long long waves, int nsx, int wps, const char* __restrict__ da, int da_cs,
     int da_co, const char* __restrict__ y, int y_cs, int y_co, const char* __restrict__ x, int x_cs, int x_co,
     const float* __restrict__ wt, int c_real, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ coef,
-    char* __restrict__ dx, int dx_cs, int dx_co, float* __restrict__ partial) {
+    char* __restrict__ dx, int dx_cs, int dx_co, float* __restrict__ partial, DwsPrev pv) {
   const int ncg = C / 4;
   const int lane = threadIdx.x & 63;
   const int xi = lane >> 2;
@@ -890,6 +901,18 @@ __global__ __launch_bounds__(256) void dwblock_bwd_strip_kernel(
   DwbRaw raw[DWS_PF];
 #pragma unroll
   for (int e = 0; e < DWS_PF; ++e) fetch(e, raw[e]);
+  // yq of the row of step e + 1 is read at step e and used at step e + 3, when that row's dx is stored
+  const char* yqp = PREV ? pv.yq + (((r0 * Wp + xcol) * pv.cs + pv.co + c0) * 2) : nullptr;
+  const long long yq_row = PREV ? (long long)pv.cs * 2 * Wp : 0;
+  U2 rawq[3] = {};
+  float qs[2][4], qmu[4], qis[4];
+  if constexpr (PREV) {
+    const float4 m4 = *(const float4*)(pv.mean + c0), i4 = *(const float4*)(pv.invstd + c0);
+    qmu[0] = m4.x; qmu[1] = m4.y; qmu[2] = m4.z; qmu[3] = m4.w;
+    qis[0] = i4.x; qis[1] = i4.y; qis[2] = i4.z; qis[3] = i4.w;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) qs[0][j] = qs[1][j] = 0.f;
+  }
   // (the rows' first loads are on their way while the parameters are read)
   if (c0 + 4 <= c_real) {                                     // 36 consecutive floats: nine 16-byte loads
     const float4* wp4 = (const float4*)(wt + c0 * 9);
@@ -987,13 +1010,28 @@ __global__ __launch_bounds__(256) void dwblock_bwd_strip_kernel(
       t = fmaf(hc[j], w[7][j], t);
       part_b[j] = fmaf(hl[j], w[8][j], t);
     }
-    if (core & (e >= 3) & (e - 2 <= nr)) {
-      U2 ov;
-      ov.x = pack2(o[0], o[1]);
-      ov.y = pack2(o[2], o[3]);
-      *(U2*)op = ov;
-    }
+    U2 ov;
+    ov.x = pack2(o[0], o[1]);
+    ov.y = pack2(o[2], o[3]);
+    if (core & (e >= 3) & (e - 2 <= nr)) *(U2*)op = ov;
     op += orow;
+    if constexpr (PREV) {
+      // xr of the stored row is the block input where this lane stores and 0 elsewhere (other lanes' columns, other
+      // strips' rows, padding): exactly the positions whose dx counts, once
+      float dr[4], vq[4];
+      unpack4(ov, dr);
+      unpack4h(rawq[S2], vq);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d = xr[S2][j] > 0.f ? dr[j] : 0.f;
+        qs[0][j] += d;
+        qs[1][j] += d * (vq[j] - qmu[j]) * qis[j];
+      }
+      if constexpr (decltype(with_fetch)::value) {
+        rawq[S2] = *(const U2*)yqp;
+        yqp += (e + 1 < left) ? yq_row : 0;
+      }
+    }
     ok_a = ok_h;
     ok_h = ok;
 #pragma unroll
@@ -1037,6 +1075,25 @@ __global__ __launch_bounds__(256) void dwblock_bwd_strip_kernel(
 #pragma unroll
     for (int t = 0; t < 9; ++t) *(float4*)(prow + t * C) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
   }
+  if constexpr (PREV) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v = qs[k][j];
+#pragma unroll
+        for (int sh8 = 32; sh8 >= 4; sh8 >>= 1) {
+          const float o = lane_read((lane + sh8) * 4, v);
+          v += (lane + sh8 < 64) ? o : 0.f;
+        }
+        qs[k][j] = v;
+      }
+    if (live & (xi == 0)) {
+      float* qrow = pv.partial + ((strip * nsx + sx) * 2) * C + c0;
+      *(float4*)qrow = make_float4(qs[0][0], qs[0][1], qs[0][2], qs[0][3]);
+      *(float4*)(qrow + C) = make_float4(qs[1][0], qs[1][1], qs[1][2], qs[1][3]);
+    }
+  }
 }
 
 // UNET_AMD_DWBLOCK_LDS=1: the workgroup kernel with the LDS exchange instead of the strip walk.  Read at every call
@@ -1055,34 +1112,64 @@ extern "C" int uh_dwblock_bwd_parts(int B, int H, int W, int C) {
   return (int)dwb_grid(B, H, W, C).x;
 }
 
-extern "C" int uh_dwblock_bwd(int B, int H, int W, int C, const void* da, int da_cstride, int da_coff, const void* y,
-                              int y_cstride, int y_coff, const void* x, int x_cstride, int x_coff, const float* w,
-                              int c_real, const float* mean, const float* invstd, const float* scale,
+static int dwblock_bwd_launch(const char* what, int B, int H, int W, int C, const void* da, int da_cstride, int da_coff,
+                              const void* y, int y_cstride, int y_coff, const void* x, int x_cstride, int x_coff,
+                              const float* w, int c_real, const float* mean, const float* invstd, const float* scale,
                               const float* shift, const float* coef, void* dx, int dx_cstride, int dx_coff,
-                              float* partial, uh_stream s) {
+                              float* partial, const DwsPrev* pv, uh_stream s) {
   UH_REQUIRE(B > 0 && H > 0 && W > 0 && da && y && x && w && mean && invstd && scale && shift && coef && dx && partial,
-             "dwblock_bwd: bad arguments");
-  UH_REQUIRE(C >= 8 && C <= 512 && (C & (C - 1)) == 0, "dwblock_bwd: C=%d must be a power of two in [8,512]", C);
-  UH_REQUIRE(c_real > 0 && c_real <= C, "dwblock_bwd: c_real=%d of C=%d", c_real, C);
+             "%s: bad arguments", what);
+  UH_REQUIRE(C >= 8 && C <= 512 && (C & (C - 1)) == 0, "%s: C=%d must be a power of two in [8,512]", what, C);
+  UH_REQUIRE(c_real > 0 && c_real <= C, "%s: c_real=%d of C=%d", what, c_real, C);
   UH_REQUIRE(da_cstride % 4 == 0 && da_coff % 4 == 0 && y_cstride % 4 == 0 && y_coff % 4 == 0 && x_cstride % 4 == 0 &&
-                 x_coff % 4 == 0 && dx_cstride % 4 == 0 && dx_coff % 4 == 0, "dwblock_bwd: bad views");
+                 x_coff % 4 == 0 && dx_cstride % 4 == 0 && dx_coff % 4 == 0, "%s: bad views", what);
   const long long Mp = uh_mp(B, H, W);
   if (dwb_use_strip()) {
     const DwsGeo g = dws_geo(B, H, W, C);
-    UH_REQUIRE(g.strips * g.nsx < (1ll << 31) && (g.waves + 3) / 4 + 8 < (1ll << 31), "dwblock_bwd: %lld waves", g.waves);
-    auto* kern = dwblock_bwd_strip_kernel<DWS_R>;
+    UH_REQUIRE(g.strips * g.nsx < (1ll << 31) && (g.waves + 3) / 4 + 8 < (1ll << 31), "%s: %lld waves", what, g.waves);
+    auto* kern = pv ? dwblock_bwd_strip_kernel<DWS_R, true> : dwblock_bwd_strip_kernel<DWS_R, false>;
     hipLaunchKernelGGL(kern, dim3((unsigned)(((g.waves + 3) / 4 + 7) / 8 * 8)), dim3(256), 0, (hipStream_t)s, Mp, C,
                        W + 1, H + 1, g.waves, g.nsx, g.wps, (const char*)da, da_cstride, da_coff, (const char*)y, y_cstride,
                        y_coff, (const char*)x, x_cstride, x_coff, w, c_real, mean, invstd, scale, shift, coef, (char*)dx,
-                       dx_cstride, dx_coff, partial);
-    return uh_check_launch("dwblock_bwd");
+                       dx_cstride, dx_coff, partial, pv ? *pv : DwsPrev{});
+    return uh_check_launch(what);
   }
+  UH_REQUIRE(!pv, "%s: only the strip walk takes the previous block's sums (UNET_AMD_DWBLOCK_LDS is set)", what);
   const int xt = 256 / (C / 4);
   hipLaunchKernelGGL(dwblock_bwd_kernel, dwb_grid(B, H, W, C), dim3(256), (size_t)xt * 9 * C * 4, (hipStream_t)s, Mp, C,
                      W + 1, H + 1, (const char*)da, da_cstride, da_coff, (const char*)y, y_cstride, y_coff,
                      (const char*)x, x_cstride, x_coff, w, c_real, mean, invstd, scale, shift, coef, (char*)dx,
                      dx_cstride, dx_coff, partial);
-  return uh_check_launch("dwblock_bwd");
+  return uh_check_launch(what);
+}
+
+extern "C" int uh_dwblock_bwd(int B, int H, int W, int C, const void* da, int da_cstride, int da_coff, const void* y,
+                              int y_cstride, int y_coff, const void* x, int x_cstride, int x_coff, const float* w,
+                              int c_real, const float* mean, const float* invstd, const float* scale,
+                              const float* shift, const float* coef, void* dx, int dx_cstride, int dx_coff,
+                              float* partial, uh_stream s) {
+  return dwblock_bwd_launch("dwblock_bwd", B, H, W, C, da, da_cstride, da_coff, y, y_cstride, y_coff, x, x_cstride, x_coff,
+                            w, c_real, mean, invstd, scale, shift, coef, dx, dx_cstride, dx_coff, partial, nullptr, s);
+}
+
+// 1 when uh_dwblock_bwd_prev can be called (the strip walk is in use), else 0
+extern "C" int uh_dwblock_bwd_takes_prev(void) { return dwb_use_strip() ? 1 : 0; }
+
+// uh_dwblock_bwd for a block whose input x is the OUTPUT of another depthwise block (x = relu(bn(yq) + that block's
+// input), nothing else reads it): also writes that block's BatchNorm-backward partial sums, the ones
+// uh_bn_res_relu_bwd_reduce would make from dx, yq and its input, to prev_partial[uh_dwblock_bwd_parts][2][C]
+// (uh_bn_bwd_finalize reduces them).  mean_q / invstd_q are that block's batch statistics.
+extern "C" int uh_dwblock_bwd_prev(int B, int H, int W, int C, const void* da, int da_cstride, int da_coff, const void* y,
+                                   int y_cstride, int y_coff, const void* x, int x_cstride, int x_coff, const float* w,
+                                   int c_real, const float* mean, const float* invstd, const float* scale,
+                                   const float* shift, const float* coef, void* dx, int dx_cstride, int dx_coff,
+                                   float* partial, const void* yq, int yq_cstride, int yq_coff, const float* mean_q,
+                                   const float* invstd_q, float* prev_partial, uh_stream s) {
+  UH_REQUIRE(yq && mean_q && invstd_q && prev_partial && yq_cstride % 4 == 0 && yq_coff % 4 == 0 && yq_cstride >= yq_coff + C,
+             "dwblock_bwd_prev: bad arguments");
+  const DwsPrev pv{(const char*)yq, yq_cstride, yq_coff, mean_q, invstd_q, prev_partial};
+  return dwblock_bwd_launch("dwblock_bwd_prev", B, H, W, C, da, da_cstride, da_coff, y, y_cstride, y_coff, x, x_cstride,
+                            x_coff, w, c_real, mean, invstd, scale, shift, coef, dx, dx_cstride, dx_coff, partial, &pv, s);
 }
 
 // partial[P][9][C] -> the module's own weight-gradient layout out[c_real][1][3][3] (padding channels dropped)

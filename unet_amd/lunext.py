@@ -27,6 +27,9 @@ L = _lib.lib
 # UNET_AMD_LUNEXT_FUSED_DW=0: the backward of a DepthwiseConvBlock behind its BatchNorm sums runs as three passes
 # (uh_bn_res_relu_bwd_apply, uh_dwconv3x3_dgrad, uh_dwconv3x3_wgrad) instead of one (uh_dwblock_bwd).
 FUSED_DW_BWD = os.environ.get("UNET_AMD_LUNEXT_FUSED_DW", "1") == "1"
+# UNET_AMD_LUNEXT_PAIR_SUMS=0: the first block of a pair makes its BatchNorm-backward sums in a pass of its own
+# (uh_bn_res_relu_bwd_reduce) instead of getting them from the second block's backward (uh_dwblock_bwd_prev).
+PAIR_SUMS = os.environ.get("UNET_AMD_LUNEXT_PAIR_SUMS", "1") == "1"
 
 
 def _padc(c):
@@ -80,6 +83,7 @@ class LUNeXtRun:
         self.recs = {}
         self.saved = {}
         self._side_used = None
+        self._bn_sums = {}
         self.packer = lunext_packer_for(module, x.device)       # bf16 GEMM operands, one repack launch per direction
         self.wf = None
         # set by a caller that keeps all parameter gradients in one flat buffer (dp.FlatGrads, laid out by
@@ -153,26 +157,35 @@ class LUNeXtRun:
         return a
 
     @ranged(lambda name, *a: "bwd/" + name)
-    def _dw_backward(self, name, da, grads):
+    def _dw_backward(self, name, da, grads, prev=None):
+        """`prev`: name of the depthwise block whose output is this block's input and is read by nothing else (the
+        first block of a pair).  Its BatchNorm-backward sums are then taken while this block's input gradient is
+        stored (uh_dwblock_bwd_prev), and its own _dw_backward call finds them in self._bn_sums."""
         rec = self.recs[name]
         B, H, W = self.geo[rec.lvl]
         C, Cp, x, y = rec.C, rec.Cp, rec.x, rec.y
         s, Ls = self._sh, self.lease
         mask = self.masks[rec.lvl]
-        parts = L.uh_bn_bwd_parts(x.Mp, Cp)
         st = (rec.mean.data_ptr(), rec.invstd.data_ptr(), rec.scale.data_ptr(), rec.shift.data_ptr())
         coef = Ls.f32(2 * Cp)
         if self.gflat is not None:
             dgam, dbet = self.gflat.views[name + ".bn.weight"], self.gflat.views[name + ".bn.bias"]
         else:
             dgam, dbet = torch.empty(2, C, dtype=torch.float32, device=self.device).unbind(0)
-        if fused_finalize():                        # sums and their finalisation in one launch
+        ready = self._bn_sums.pop(name, None)
+        if ready is not None:                        # the block after this one has left the sums behind
+            partial, parts = ready
+            call("uh_bn_bwd_finalize", partial.data_ptr(), parts, Cp, C, B * H * W, dgam.data_ptr(), dbet.data_ptr(),
+                 coef.data_ptr(), 0, s)
+        elif fused_finalize():                      # sums and their finalisation in one launch
+            parts = L.uh_bn_bwd_parts(x.Mp, Cp)
             nbytes = L.uh_fin_ws_bytes(parts, Cp, 2)
             ws = Ls.f32((nbytes + 3) // 4)
             call("uh_bn_res_relu_bwd_reduce_fin", x.Mp, Cp, da.ptr, da.cstride, da.coff, y.ptr, y.cstride, y.coff,
                  x.ptr, x.cstride, x.coff, *st, C, B * H * W, dgam.data_ptr(), dbet.data_ptr(), coef.data_ptr(),
                  ws.data_ptr(), nbytes, self.pool.counters(s).data_ptr(), s)
         else:
+            parts = L.uh_bn_bwd_parts(x.Mp, Cp)
             partial = Ls.f32(parts * 2 * Cp)
             call("uh_bn_res_relu_bwd_reduce", x.Mp, Cp, da.ptr, da.cstride, da.coff, y.ptr, y.cstride, y.coff, x.ptr,
                  x.cstride, x.coff, *st, partial.data_ptr(), s)
@@ -184,9 +197,18 @@ class LUNeXtRun:
             wp = Ls.f32(wparts * 9 * Cp)
             dx = Ls.act(B, H, W, Cp)
             dw = self._gnew(name + ".depthwise.weight", (C, 1, 3, 3))
-            call("uh_dwblock_bwd", B, H, W, Cp, da.ptr, da.cstride, da.coff, y.ptr, y.cstride, y.coff, x.ptr,
-                 x.cstride, x.coff, rec.wt.data_ptr(), C, *st, coef.data_ptr(), dx.ptr, dx.cstride,
-                 dx.coff, wp.data_ptr(), s)
+            q = self.recs.get(prev) if PAIR_SUMS and prev is not None and L.uh_dwblock_bwd_takes_prev() else None
+            if q is not None and q.a is x and q.Cp == Cp:
+                qpart = Ls.f32(wparts * 2 * Cp)
+                call("uh_dwblock_bwd_prev", B, H, W, Cp, da.ptr, da.cstride, da.coff, y.ptr, y.cstride, y.coff, x.ptr,
+                     x.cstride, x.coff, rec.wt.data_ptr(), C, *st, coef.data_ptr(), dx.ptr, dx.cstride,
+                     dx.coff, wp.data_ptr(), q.y.ptr, q.y.cstride, q.y.coff, q.mean.data_ptr(), q.invstd.data_ptr(),
+                     qpart.data_ptr(), s)
+                self._bn_sums[prev] = (qpart, wparts)
+            else:
+                call("uh_dwblock_bwd", B, H, W, Cp, da.ptr, da.cstride, da.coff, y.ptr, y.cstride, y.coff, x.ptr,
+                     x.cstride, x.coff, rec.wt.data_ptr(), C, *st, coef.data_ptr(), dx.ptr, dx.cstride,
+                     dx.coff, wp.data_ptr(), s)
             with self._side() as s2:
                 call("uh_dw_wgrad_finalize", wp.data_ptr(), wparts, Cp, C, dw.data_ptr(), s2)
             grads[name + ".depthwise.weight"] = dw
@@ -563,16 +585,16 @@ class LUNeXtRun:
         self._skip_ready = {}
         for k in range(4, 0, -1):
             l = 4 - k
-            da = self._dw_backward(f"conv_up{k}_1", self._dw_backward(f"conv_up{k}_2", da, grads), grads)
+            da = self._dw_backward(f"conv_up{k}_1", self._dw_backward(f"conv_up{k}_2", da, grads, prev=f"conv_up{k}_1"), grads)
             dg, dx = self._gate_backward(k, da, grads)
             skip_grads[l] = dx
             da = self._up_backward(k, dg, grads)
-        da = self._dw_backward("conv5_1", self._dw_backward("conv5_2", da, grads), grads)
+        da = self._dw_backward("conv5_1", self._dw_backward("conv5_2", da, grads, prev="conv5_1"), grads)
         for l in range(4, 0, -1):
             if (l - 1) in self._skip_ready:
                 self._main.wait_event(self._skip_ready[l - 1])
             tot = self._down_backward(l, da, grads, skip_grads[l - 1])
-            da = self._dw_backward(f"conv{l}_1", self._dw_backward(f"conv{l}_2", tot, grads), grads)
+            da = self._dw_backward(f"conv{l}_1", self._dw_backward(f"conv{l}_2", tot, grads, prev=f"conv{l}_1"), grads)
         if self._side_used is not None:
             self._main.wait_stream(self._side_used)
         return grads
