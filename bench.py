@@ -348,7 +348,7 @@ def main():
                             "ms_per_step": round(v["ms"] / instrumented, 3),
                             "launches_per_step": v["launches"] // instrumented} for k, v in ks.items()},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:         # timed on the host cores of a one-GPU run only
             out["cpu_baseline"] = cpu_baseline(min(16, os.cpu_count() or 1) if "OMP_NUM_THREADS" not in os.environ
                                                else int(os.environ["OMP_NUM_THREADS"]))
         if world == 1 and not args.no_second_workload and args.size == IMG and args.batch == BATCH_PER_GPU:
