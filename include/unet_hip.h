@@ -281,12 +281,15 @@ int uh_head_bwd_bnstat(int B, int H, int W, int C, int OC, const void* a, int a_
 
 /* ---- LUNeXt blocks (models/lunext.py), padded-linear NHWC bf16 with C a multiple of 8 ----------------
  * The 3-channel full-resolution level is carried zero-padded to 8 channels. */
-/* workgroups (= rows of `partial`) of the depthwise forward and weight-gradient kernels */
+/* rows of `partial` of the depthwise weight-gradient kernel, of uh_dwconv3x3_fwd_bn and of the eval-mode forward */
 int uh_dw_parts(int B, int H, int W, int C);
+/* rows of `partial` that uh_dwconv3x3_fwd writes in RAW_STATS mode (the training forward runs as a per-wave strip walk,
+ * one row per strip and column block; UNET_AMD_DWFWD_TILES=1: the one-thread-per-column kernel, uh_dw_parts rows) */
+int uh_dwconv3x3_fwd_parts(int B, int H, int W, int C);
 /* depthwise Conv2d(C,C,3,pad 1,groups=C) (lunext.py:14-15,24).  w and bias are the module's own fp32 tensors
  * ([c_real][1][3][3] and [c_real], 16-byte aligned); channels c_real..C-1 of the activations are zero padding.
- * RAW_STATS: out = fp16(v) and partial[blk][2][C] = (sum v, sum v^2); AFFINE_RELU: out = relu(v*scale + shift + x)
- * (eval-mode block; scale, shift of C floats). */
+ * RAW_STATS: out = fp16(v) and partial[uh_dwconv3x3_fwd_parts][2][C] = (sum v, sum v^2); AFFINE_RELU:
+ * out = relu(v*scale + shift + x) (eval-mode block; scale, shift of C floats). */
 int uh_dwconv3x3_fwd(int B, int H, int W, int C, const void* x, int x_cstride, int x_coff,
                      const float* w, int c_real, const float* bias, int mode, const float* scale, const float* shift,
                      const uint8_t* rowmask, void* out, int o_cstride, int o_coff, float* partial, uh_stream s);

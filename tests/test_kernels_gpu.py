@@ -503,7 +503,7 @@ def test_adam_step_matches_torch():
 
 
 @pytest.mark.parametrize("B,H,W,C", [(2, 16, 16, 64), (1, 20, 12, 8), (3, 5, 7, 24), (2, 33, 31, 128), (1, 48, 48, 512)])
-def test_depthwise_conv_forward_backward(B, H, W, C):
+def test_depthwise_conv_forward_backward(B, H, W, C, monkeypatch):
     """uh_dwconv3x3_fwd (both epilogues) / _dgrad / _wgrad against F.conv2d(groups=C) on the same bf16-rounded
     operands; shapes whose rows do not fill the 16-row strips and whose width does not fill a workgroup."""
     g = torch.Generator().manual_seed(B * 100 + H + C)
@@ -515,12 +515,24 @@ def test_depthwise_conv_forward_backward(B, H, W, C):
     mask = rowmask(B, H, W)
     parts = lib.uh_dw_parts(B, H, W, C)
     assert parts > 0 and lib.uh_dw_parts(B, H, W, C + 1) == 0
-    stat = torch.full((parts, 2, C), float("nan"), device=DEV)
+    fparts = lib.uh_dwconv3x3_fwd_parts(B, H, W, C)
+    assert fparts > 0 and lib.uh_dwconv3x3_fwd_parts(B, H, W, C + 1) == 0
+    stat = torch.full((fparts, 2, C), float("nan"), device=DEV)
     y = new_act(B, H, W, C, DEV)
     bd = bias.to(DEV)
     call("uh_dwconv3x3_fwd", B, H, W, C, xa.ptr, xa.cstride, xa.coff, wd.data_ptr(), C, bd.data_ptr(), _lib.EPI_RAW_STATS,
          None, None, mask.data_ptr(), y.ptr, y.cstride, y.coff, stat.data_ptr(), S())
+    # the one-thread-per-column kernel (UNET_AMD_DWFWD_TILES=1; the only one where C is not a power of two): same bits
+    monkeypatch.setenv("UNET_AMD_DWFWD_TILES", "1")
+    assert lib.uh_dwconv3x3_fwd_parts(B, H, W, C) == parts
+    stat_t = torch.full((parts, 2, C), float("nan"), device=DEV)
+    y_t = new_act(B, H, W, C, DEV)
+    call("uh_dwconv3x3_fwd", B, H, W, C, xa.ptr, xa.cstride, xa.coff, wd.data_ptr(), C, bd.data_ptr(), _lib.EPI_RAW_STATS,
+         None, None, mask.data_ptr(), y_t.ptr, y_t.cstride, y_t.coff, stat_t.data_ptr(), S())
+    monkeypatch.delenv("UNET_AMD_DWFWD_TILES")
     torch.cuda.synchronize()
+    assert torch.equal(y.buf, y_t.buf), "strip walk and tile kernel disagree on y"
+    torch.testing.assert_close(stat.sum(0), stat_t.sum(0), rtol=2e-5, atol=1e-3)
     want = F.conv2d(x, w, bias, padding=1, groups=C)
     close(y.to_nchw(half=True), want, 1e-3, "depthwise output (fp16 store)")
     pads_are_zero(y)
@@ -572,7 +584,7 @@ def test_depthwise_conv_padded_channels():
     wd, bd = w.to(DEV), bias.to(DEV)
     mask = rowmask(B, H, W)
     parts = lib.uh_dw_parts(B, H, W, Cp)
-    stat = torch.zeros(parts, 2, Cp, device=DEV)
+    stat = torch.zeros(lib.uh_dwconv3x3_fwd_parts(B, H, W, Cp), 2, Cp, device=DEV)
     y = new_act(B, H, W, Cp, DEV)
     call("uh_dwconv3x3_fwd", B, H, W, Cp, xa.ptr, xa.cstride, xa.coff, wd.data_ptr(), C, bd.data_ptr(), _lib.EPI_RAW_STATS,
          None, None, mask.data_ptr(), y.ptr, y.cstride, y.coff, stat.data_ptr(), S())
@@ -1201,10 +1213,11 @@ def test_depthwise_forward_with_batchnorm_finalised_inside(B, H, W, C, c_real):
                     rm=torch.zeros(c_real, device=DEV), rv=torch.ones(c_real, device=DEV),
                     nbt=torch.zeros((), dtype=torch.int64, device=DEV))
     a = fresh()
-    stat = torch.empty(parts, 2, C, device=DEV)
+    fparts = lib.uh_dwconv3x3_fwd_parts(B, H, W, C)
+    stat = torch.empty(fparts, 2, C, device=DEV)
     call("uh_dwconv3x3_fwd", B, H, W, C, xa.ptr, xa.cstride, xa.coff, w.data_ptr(), c_real, bias.data_ptr(),
          _lib.EPI_RAW_STATS, None, None, mask.data_ptr(), a["y"].ptr, a["y"].cstride, a["y"].coff, stat.data_ptr(), S())
-    call("uh_bn_finalize", stat.data_ptr(), parts, C, c_real, B * H * W, gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.1,
+    call("uh_bn_finalize", stat.data_ptr(), fparts, C, c_real, B * H * W, gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.1,
          a["f"][0].data_ptr(), a["f"][1].data_ptr(), a["f"][2].data_ptr(), a["f"][3].data_ptr(), a["rm"].data_ptr(),
          a["rv"].data_ptr(), a["nbt"].data_ptr(), S())
     outs = []

@@ -12,7 +12,7 @@ for (B, H, W, C, cr) in [(32, 256, 256, 8, 3), (32, 128, 128, 64, 64), (32, 64, 
     x.fill_from_nchw(torch.randn(B, C, H, W).to(DEV))
     wt, bias = torch.randn(cr, 1, 3, 3, device=DEV), torch.randn(cr, device=DEV)
     mask = pool_for(DEV).rowmask(B, H, W)
-    parts = lib.uh_dw_parts(B, H, W, C)
+    parts = lib.uh_dwconv3x3_fwd_parts(B, H, W, C)
     stat = torch.empty(parts * 2 * C, device=DEV)
     f = lambda: call("uh_dwconv3x3_fwd", B, H, W, C, x.ptr, x.cstride, x.coff, wt.data_ptr(), cr, bias.data_ptr(), _lib.EPI_RAW_STATS,
                      None, None, mask.data_ptr(), y.ptr, y.cstride, y.coff, stat.data_ptr(), S())

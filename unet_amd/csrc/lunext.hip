@@ -184,6 +184,12 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(long long Mp, int C, in
   }
 }
 
+// the training forward as a per-wave strip walk (dwconv_fwd_strip_kernel, further down)
+static bool dwf_use_strip(int C);
+static int dwconv_fwd_strip_launch(int B, int H, int W, int C, const void* x, int x_cstride, int x_coff, const float* w,
+                                   int c_real, const float* bias, void* out, int o_cstride, int o_coff, float* partial,
+                                   uh_stream s);
+
 extern "C" int uh_dw_parts(int B, int H, int W, int C) {
   if (!(B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && C / 8 <= 256)) return 0;
   return (int)dw_grid(B, H, W, C).x;
@@ -199,6 +205,8 @@ extern "C" int uh_dwconv3x3_fwd(int B, int H, int W, int C, const void* x, int x
   UH_REQUIRE(mode == UH_EPI_RAW_STATS || mode == UH_EPI_AFFINE_RELU, "dwconv3x3_fwd: bad mode %d", mode);
   UH_REQUIRE(mode != UH_EPI_RAW_STATS || partial, "dwconv3x3_fwd: RAW_STATS needs partial");
   UH_REQUIRE(mode != UH_EPI_AFFINE_RELU || (scale && shift), "dwconv3x3_fwd: AFFINE_RELU needs scale/shift");
+  if (mode == UH_EPI_RAW_STATS && dwf_use_strip(C))
+    return dwconv_fwd_strip_launch(B, H, W, C, x, x_cstride, x_coff, w, c_real, bias, out, o_cstride, o_coff, partial, s);
   const long long Mp = uh_mp(B, H, W);
   const int rpi = ew_rows_per_iter(C);
   BnFwdFin fin{};
@@ -801,6 +809,35 @@ __global__ __launch_bounds__(256) void dwblock_bwd_kernel(
 __device__ __forceinline__ float lane_read(int byte_addr, float v) {          // v of lane byte_addr / 4
   return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_addr, __builtin_bit_cast(int, v)));
 }
+// Per-lane sums v[N][4] (N quantities x this lane's four channels; lanes that own nothing hold zeros) -> one row of
+// table[rows][N][C]: the 16 columns of a pair are added in a fixed order; with two channel groups (C = 8) the wave's two
+// column blocks as well, so that the table has one row per strip and PAIR of column blocks (half as many rows for the
+// finalisation launch to add up, which is a chain of loads per row).
+__host__ __device__ __forceinline__ int dws_rows_per_strip(int nsx, int ncg) { return ncg == 2 ? (nsx + 1) / 2 : nsx; }
+template <int N>
+__device__ __forceinline__ void dws_store_row(float (&v)[N][4], int lane, bool live, int ncg, int nsx, long long strip,
+                                              int sx, int C, int c0, float* __restrict__ table) {
+#pragma unroll
+  for (int k = 0; k < N; ++k)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float a = v[k][j];
+#pragma unroll
+      for (int sh8 = 32; sh8 >= 4; sh8 >>= 1) {
+        const float o = lane_read((lane + sh8) * 4, a);
+        a += (lane + sh8 < 64) ? o : 0.f;
+      }
+      if (ncg == 2) a += lane_read((lane + 2) * 4, a);      // (read by lanes 0 and 1 only: lanes 2 and 3 exist)
+      v[k][j] = a;
+    }
+  const bool writer = live & (lane < (ncg == 2 ? 2 : 4));
+  if (writer) {
+    const long long row = ncg == 2 ? strip * ((nsx + 1) / 2) + (sx >> 1) : strip * nsx + sx;
+    float* dst = table + (row * N) * C + c0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) *(float4*)(dst + (long long)k * C) = make_float4(v[k][0], v[k][1], v[k][2], v[k][3]);
+  }
+}
 
 struct DwsGeo {
   long long strips, waves;
@@ -1056,44 +1093,174 @@ __global__ __launch_bounds__(256) void dwblock_bwd_strip_kernel(
   step(std::integral_constant<int, 0>{}, No{}, R);
   step(std::integral_constant<int, 1>{}, No{}, R + 1);
   step(std::integral_constant<int, 2>{}, No{}, R + 2);
-  // the 16 columns of a pair add their weight-gradient sums (halo lanes hold zeros) in a fixed order: lanes 0..3 end
-  // up with the totals of the four pairs
-  float* prow = partial + ((strip * nsx + sx) * 9) * C + c0;
+  dws_store_row<9>(acc, lane, live, ncg, nsx, strip, sx, C, c0, partial);
+  if constexpr (PREV) dws_store_row<2>(qs, lane, live, ncg, nsx, strip, sx, C, c0, pv.partial);
+}
+
+// ---- the depthwise forward of a training step as the same kind of walk ------------------------------------------------
+// y = fp16(dwconv3x3(x) + bias) and the BatchNorm sums (sum y, sum y^2) per (strip, column block).  A row of x is met
+// once: it starts the output row below it (top taps), extends its own (middle taps) and finishes the one above (bottom
+// taps) -- the taps of an output are added in dwconv_fwd_kernel's order (bias, then row-major), so y has the same bits.
+// One 8-byte load per lane and row instead of three 16-byte ones; lanes, strips and the one-step delay of the exchanged
+// values as in dwblock_bwd_strip_kernel.
+template <int R>
+__global__ __launch_bounds__(256) void dwconv_fwd_strip_kernel(
+    long long Mp, int C, int Wp, int Hp, long long waves, int nsx, int wps, const char* __restrict__ x, int x_cs, int x_co,
+    const float* __restrict__ wt, int c_real, const float* __restrict__ bias, char* __restrict__ out, int o_cs, int o_co,
+    float* __restrict__ partial) {
+  const int ncg = C / 4;
+  const int lane = threadIdx.x & 63;
+  const int xi = lane >> 2;
+  const long long blk = (long long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const long long wv = blk * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (wv >= waves) return;
+  const long long strip = wv / wps;
+  const int q = (int)(wv % wps) * 4 + (lane & 3);
+  const int left_lane = (lane - 4) * 4, right_lane = (lane + 4) * 4;
+  const bool live = q < nsx * ncg;
+  const int qc = live ? q : 0;
+  const int cg = qc % ncg, sx = qc / ncg;
+  const int c0 = cg * 4;
+  const long long rows = Mp / Wp;
+  const long long r0 = strip * R;
+  const int xcol = sx * DWS_CORE - 1 + xi;
+  const bool core = live & (xi >= 1) & (xi <= DWS_CORE) & (xcol < Wp);
+  const bool col_in = live & (xcol >= 0) & (xcol < Wp - 1);
+  const long long left_ll = rows - r0;
+  const int left = (int)(left_ll < (1 << 20) ? left_ll : (1 << 20));
+  const int nr = left < R ? left : R;
+  const char* xp = x + ((((r0 - 1) * Wp + xcol) * x_cs + x_co + c0) * 2);
+  const long long x_row = (long long)x_cs * 2 * Wp;
+  auto fetch = [&](int e, U2& t) {
+    t = *(const U2*)xp;
+    xp += (e <= left) ? x_row : 0;
+  };
+  U2 raw[DWS_PF];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int e = 0; e < DWS_PF; ++e) fetch(e, raw[e]);
+  float w[9][4], b[4], acc[2][4];
+  if (c0 + 4 <= c_real) {
+    const float4* wp4 = (const float4*)(wt + c0 * 9);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const float4 v4 = wp4[i];
+      const float f[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) w[(i * 4 + k) % 9][(i * 4 + k) / 9] = f[k];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int c = c0 + j;
+        const float wv9 = wt[(c < c_real ? c : c_real - 1) * 9 + t];
+        w[t][j] = (c < c_real) ? wv9 : 0.f;
+      }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = c0 + j;
+    const float bv = bias ? bias[c < c_real ? c : c_real - 1] : 0.f;
+    b[j] = ((bias != nullptr) & (c < c_real)) ? bv : 0.f;
+    acc[0][j] = acc[1][j] = 0.f;
+  }
+  int ry_u = (int)((r0 + Hp - 1) % Hp);                       // image row of the row the next step meets
+  float part_a[4], part_b[4], hc[4], hl[4], hr[4];            // output rows e - 2 and e - 1 so far; x of the row of step e - 1
+  bool ok_a = false, ok_h = false;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) part_a[j] = part_b[j] = hc[j] = hl[j] = hr[j] = 0.f;
+  char* op = out + (((r0 - 3) * Wp + xcol) * o_cs + o_co + c0) * 2;          // step e finishes the row of step e - 2
+  const long long orow = (long long)o_cs * 2 * Wp;
+  auto step = [&](auto ph, auto with_fetch, int e) {
+    constexpr int S0 = decltype(ph)::value;
+    const bool ok = (e <= left) & (ry_u != Hp - 1) & (e <= R + 1) & col_in;
+    ry_u = ry_u + 1 == Hp ? 0 : ry_u + 1;
+    float c[4], nl[4], nr4[4];
+    unpack4(raw[S0], c);
+    if constexpr (decltype(with_fetch)::value) fetch(e + DWS_PF, raw[S0]);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      float v = acc[t][j];
-#pragma unroll
-      for (int sh8 = 32; sh8 >= 4; sh8 >>= 1) {
-        const float o = lane_read((lane + sh8) * 4, v);
-        v += (lane + sh8 < 64) ? o : 0.f;
-      }
-      acc[t][j] = v;
+      nl[j] = lane_read(left_lane, c[j]);
+      nr4[j] = lane_read(right_lane, c[j]);
     }
-  if (live & (xi == 0)) {
+    float v[4];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) *(float4*)(prow + t * C) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
-  }
-  if constexpr (PREV) {
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float v = qs[k][j];
-#pragma unroll
-        for (int sh8 = 32; sh8 >= 4; sh8 >>= 1) {
-          const float o = lane_read((lane + sh8) * 4, v);
-          v += (lane + sh8 < 64) ? o : 0.f;
-        }
-        qs[k][j] = v;
-      }
-    if (live & (xi == 0)) {
-      float* qrow = pv.partial + ((strip * nsx + sx) * 2) * C + c0;
-      *(float4*)qrow = make_float4(qs[0][0], qs[0][1], qs[0][2], qs[0][3]);
-      *(float4*)(qrow + C) = make_float4(qs[1][0], qs[1][1], qs[1][2], qs[1][3]);
+    for (int j = 0; j < 4; ++j) {
+      float t = part_a[j];                                    // the bottom taps finish output row e - 2
+      t = fmaf(hl[j], w[6][j], t);
+      t = fmaf(hc[j], w[7][j], t);
+      t = fmaf(hr[j], w[8][j], t);
+      v[j] = ok_a ? t : 0.f;
+      t = part_b[j];                                          // middle taps: output row e - 1
+      t = fmaf(hl[j], w[3][j], t);
+      t = fmaf(hc[j], w[4][j], t);
+      part_a[j] = fmaf(hr[j], w[5][j], t);
+      t = fmaf(hl[j], w[0][j], b[j]);                         // bias and top taps: output row e starts
+      t = fmaf(hc[j], w[1][j], t);
+      part_b[j] = fmaf(hr[j], w[2][j], t);
     }
+    const bool st = core & (e >= 3) & (e - 2 <= nr);
+    if (st) {
+      U2 ov;
+      ov.x = pack2h(v[0], v[1]);
+      ov.y = pack2h(v[2], v[3]);
+      *(U2*)op = ov;
+    }
+    op += orow;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float u = st ? v[j] : 0.f;
+      acc[0][j] += u;
+      acc[1][j] += u * u;
+      hc[j] = c[j];
+      hl[j] = nl[j];
+      hr[j] = nr4[j];
+    }
+    ok_a = ok_h;
+    ok_h = ok;
+  };
+  static_assert(R % 3 == 0 && DWS_PF == 3, "the load ring is walked three steps at a time");
+  using Yes = std::true_type;
+  using No = std::false_type;
+#pragma unroll 1
+  for (int e = 0; e < R; e += 3) {
+    step(std::integral_constant<int, 0>{}, Yes{}, e);
+    step(std::integral_constant<int, 1>{}, Yes{}, e + 1);
+    step(std::integral_constant<int, 2>{}, Yes{}, e + 2);
   }
+  step(std::integral_constant<int, 0>{}, No{}, R);
+  step(std::integral_constant<int, 1>{}, No{}, R + 1);
+  step(std::integral_constant<int, 2>{}, No{}, R + 2);
+  dws_store_row<2>(acc, lane, live, ncg, nsx, strip, sx, C, c0, partial);
+}
+
+// UNET_AMD_DWFWD_TILES=1: the training forward as dwconv_fwd_kernel (one thread per column, three loads per row)
+static bool dwf_use_strip(int C) {
+  const char* e = getenv("UNET_AMD_DWFWD_TILES");
+  return (!e || atoi(e) == 0) && C >= 8 && C <= 512 && (C & (C - 1)) == 0;
+}
+
+// rows of the partial-sum table uh_dwconv3x3_fwd writes in RAW_STATS mode (for uh_bn_finalize)
+extern "C" int uh_dwconv3x3_fwd_parts(int B, int H, int W, int C) {
+  if (!(B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && C / 8 <= 256)) return 0;
+  if (dwf_use_strip(C)) {
+    const DwsGeo g = dws_geo(B, H, W, C);
+    return (int)(g.strips * dws_rows_per_strip(g.nsx, g.ncg));
+  }
+  return (int)dw_grid(B, H, W, C).x;
+}
+
+static int dwconv_fwd_strip_launch(int B, int H, int W, int C, const void* x, int x_cstride, int x_coff, const float* w,
+                                   int c_real, const float* bias, void* out, int o_cstride, int o_coff, float* partial,
+                                   uh_stream s) {
+  UH_REQUIRE(x_cstride % 4 == 0 && x_coff % 4 == 0 && o_cstride % 4 == 0 && o_coff % 4 == 0, "dwconv3x3_fwd: bad views");
+  const DwsGeo g = dws_geo(B, H, W, C);
+  UH_REQUIRE(g.strips * g.nsx < (1ll << 31) && (g.waves + 3) / 4 + 8 < (1ll << 31), "dwconv3x3_fwd: %lld waves", g.waves);
+  hipLaunchKernelGGL(dwconv_fwd_strip_kernel<DWS_R>, dim3((unsigned)(((g.waves + 3) / 4 + 7) / 8 * 8)), dim3(256), 0,
+                     (hipStream_t)s, uh_mp(B, H, W), C, W + 1, H + 1, g.waves, g.nsx, g.wps, (const char*)x, x_cstride,
+                     x_coff, w, c_real, bias, (char*)out, o_cstride, o_coff, partial);
+  return uh_check_launch("dwconv3x3_fwd");
 }
 
 // UNET_AMD_DWBLOCK_LDS=1: the workgroup kernel with the LDS exchange instead of the strip walk.  Read at every call
@@ -1107,7 +1274,7 @@ extern "C" int uh_dwblock_bwd_parts(int B, int H, int W, int C) {
   if (!(B > 0 && H > 0 && W > 0 && C >= 8 && C <= 512 && (C & (C - 1)) == 0)) return 0;
   if (dwb_use_strip()) {
     const DwsGeo g = dws_geo(B, H, W, C);
-    return (int)(g.strips * g.nsx);
+    return (int)(g.strips * dws_rows_per_strip(g.nsx, g.ncg));
   }
   return (int)dwb_grid(B, H, W, C).x;
 }

@@ -129,7 +129,7 @@ class LUNeXtRun:
         rec = _DWRec()
         rec.name, rec.x, rec.a, rec.C, rec.Cp, rec.lvl, rec.wt = name, x, a, C, Cp, lvl, wt
         rec.y = Ls.act(B, H, W, Cp)
-        parts = L.uh_dw_parts(B, H, W, Cp)
+        parts = L.uh_dw_parts(B, H, W, Cp) if fused_finalize() else L.uh_dwconv3x3_fwd_parts(B, H, W, Cp)
         f = Ls.f32(4 * Cp)
         rec.mean, rec.invstd, rec.scale, rec.shift = f[:Cp], f[Cp:2 * Cp], f[2 * Cp:3 * Cp], f[3 * Cp:]
         # the C real channels of the parameters and running statistics are read and updated where they are
