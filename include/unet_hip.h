@@ -293,6 +293,16 @@ int uh_dwconv3x3_fwd_parts(int B, int H, int W, int C);
 int uh_dwconv3x3_fwd(int B, int H, int W, int C, const void* x, int x_cstride, int x_coff,
                      const float* w, int c_real, const float* bias, int mode, const float* scale, const float* shift,
                      const uint8_t* rowmask, void* out, int o_cstride, int o_coff, float* partial, uh_stream s);
+/* The training forward of the SECOND DepthwiseConvBlock of a pair (lunext.py:187-259 chains them two by two): its input
+ * a = relu(scale_q * yq + shift_q + xq), the first block's BatchNorm + residual + ReLU (lunext.py:27-29, what
+ * uh_bn_res_relu_apply computes), is evaluated here, written to `a` and convolved; out and partial as uh_dwconv3x3_fwd
+ * in RAW_STATS mode.  Same bits as the two launches it replaces, without reading `a` back.
+ * uh_dwconv3x3_fwd_takes_apply(C) is 1 when the kernel in use can do this for C channels. */
+int uh_dwconv3x3_fwd_takes_apply(int C);
+int uh_dwconv3x3_fwd_applied(int B, int H, int W, int C, const void* yq, int yq_cstride, int yq_coff,
+                             const void* xq, int xq_cstride, int xq_coff, const float* scale_q, const float* shift_q,
+                             void* a, int a_cstride, int a_coff, const float* w, int c_real, const float* bias,
+                             void* out, int o_cstride, int o_coff, float* partial, uh_stream s);
 /* a = relu(y*scale + shift + x)   (lunext.py:25-28) and its backward: d = da*(.. > 0);
  * reduce -> partial[P][2][C] (P = uh_bn_bwd_parts); apply -> dy = scale*(d - c0 - xhat*c1), dr = d */
 int uh_bn_res_relu_apply(long long Mp, int C, const void* y, int y_cstride, int y_coff,

@@ -854,6 +854,42 @@ def test_depthwise_block_backward_in_one_pass(B, H, W, C, c_real, monkeypatch):
 
 
 @pytest.mark.parametrize("B,H,W,C,c_real", [(2, 16, 16, 64, 64), (1, 20, 12, 8, 3), (2, 40, 30, 64, 64), (3, 37, 45, 16, 16),
+                                            (1, 3, 3, 512, 512), (2, 33, 31, 128, 128)])
+def test_depthwise_forward_applies_the_previous_block(B, H, W, C, c_real):
+    """uh_dwconv3x3_fwd_applied against uh_bn_res_relu_apply followed by uh_dwconv3x3_fwd: the activation it writes,
+    the convolution output and the partial sums, bit for bit."""
+    assert lib.uh_dwconv3x3_fwd_takes_apply(C) == 1 and lib.uh_dwconv3x3_fwd_takes_apply(24) == 0
+    g = torch.Generator().manual_seed(83)
+    live = (torch.arange(C) < c_real).float().view(1, C, 1, 1)
+    xq = act_from(bf(torch.randn(B, C, H, W, generator=g)) * live, cstride=2 * C, coff=C)
+    yq = act_from((torch.randn(B, C, H, W, generator=g) * 1.5).half().float() * live, half=True)
+    sc = ((torch.rand(C, generator=g) + 0.5) * live.view(-1)).to(DEV)
+    sh = ((torch.randn(C, generator=g) * 0.3) * live.view(-1)).to(DEV)
+    wt = (torch.randn(c_real, 1, 3, 3, generator=g) / 3).to(DEV)
+    bias = torch.randn(c_real, generator=g).to(DEV)
+    mask = rowmask(B, H, W)
+    parts = lib.uh_dwconv3x3_fwd_parts(B, H, W, C)
+    a0, a1, y0, y1 = (new_act(B, H, W, C, DEV) for _ in range(4))
+    st0 = torch.full((parts, 2, C), float("nan"), device=DEV)
+    st1 = torch.full((parts, 2, C), float("nan"), device=DEV)
+    a1.padded_rows()[:, :] = 7.0                                  # every position must be written, padding included
+    y1.padded_rows()[:, :] = 7.0
+    call("uh_bn_res_relu_apply", xq.Mp, C, yq.ptr, yq.cstride, yq.coff, xq.ptr, xq.cstride, xq.coff, sc.data_ptr(),
+         sh.data_ptr(), mask.data_ptr(), a0.ptr, a0.cstride, a0.coff, S())
+    call("uh_dwconv3x3_fwd", B, H, W, C, a0.ptr, a0.cstride, a0.coff, wt.data_ptr(), c_real, bias.data_ptr(),
+         _lib.EPI_RAW_STATS, None, None, mask.data_ptr(), y0.ptr, y0.cstride, y0.coff, st0.data_ptr(), S())
+    call("uh_dwconv3x3_fwd_applied", B, H, W, C, yq.ptr, yq.cstride, yq.coff, xq.ptr, xq.cstride, xq.coff, sc.data_ptr(),
+         sh.data_ptr(), a1.ptr, a1.cstride, a1.coff, wt.data_ptr(), c_real, bias.data_ptr(), y1.ptr, y1.cstride, y1.coff,
+         st1.data_ptr(), S())
+    torch.cuda.synchronize()
+    assert torch.equal(a0.padded_rows(), a1.padded_rows()), "activation"
+    assert torch.equal(y0.padded_rows(), y1.padded_rows()), "convolution output"
+    assert torch.equal(st0, st1), "partial sums"
+    pads_are_zero(a1)
+    pads_are_zero(y1)
+
+
+@pytest.mark.parametrize("B,H,W,C,c_real", [(2, 16, 16, 64, 64), (1, 20, 12, 8, 3), (2, 40, 30, 64, 64), (3, 37, 45, 16, 16),
                                             (1, 3, 3, 512, 512)])
 def test_depthwise_block_backward_leaves_the_previous_block_its_sums(B, H, W, C, c_real):
     """uh_dwblock_bwd_prev: same dx and weight-gradient partials as uh_dwblock_bwd, bit for bit, plus the

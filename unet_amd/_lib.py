@@ -86,6 +86,8 @@ SIGNATURES = {
     "uh_resize_bilinear_bwd": (I, [I, I, I, I, I, I, P, I, I, P, I, I, P]),
     "uh_dwblock_bwd_parts": (I, [I, I, I, I]),
     "uh_dwconv3x3_fwd_parts": (I, [I, I, I, I]),
+    "uh_dwconv3x3_fwd_takes_apply": (I, [I]),
+    "uh_dwconv3x3_fwd_applied": (I, [I, I, I, I, P, I, I, P, I, I, P, P, P, I, I, P, I, P, P, I, I, P, P]),
     "uh_dwblock_bwd": (I, [I, I, I, I, P, I, I, P, I, I, P, I, I, P, I, P, P, P, P, P, P, I, I, P, P]),
     "uh_dwblock_bwd_takes_prev": (I, []),
     "uh_dwblock_bwd_prev": (I, [I, I, I, I, P, I, I, P, I, I, P, I, I, P, I, P, P, P, P, P, P, I, I, P, P, I, I, P, P, P, P]),

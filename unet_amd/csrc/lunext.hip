@@ -186,9 +186,10 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(long long Mp, int C, in
 
 // the training forward as a per-wave strip walk (dwconv_fwd_strip_kernel, further down)
 static bool dwf_use_strip(int C);
+struct DwfApply;
 static int dwconv_fwd_strip_launch(int B, int H, int W, int C, const void* x, int x_cstride, int x_coff, const float* w,
                                    int c_real, const float* bias, void* out, int o_cstride, int o_coff, float* partial,
-                                   uh_stream s);
+                                   uh_stream s, const DwfApply* ap = nullptr);
 
 extern "C" int uh_dw_parts(int B, int H, int W, int C) {
   if (!(B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && C / 8 <= 256)) return 0;
@@ -1103,11 +1104,23 @@ __global__ __launch_bounds__(256) void dwblock_bwd_strip_kernel(
 // taps) -- the taps of an output are added in dwconv_fwd_kernel's order (bias, then row-major), so y has the same bits.
 // One 8-byte load per lane and row instead of three 16-byte ones; lanes, strips and the one-step delay of the exchanged
 // values as in dwblock_bwd_strip_kernel.
-template <int R>
+// APPLY: the convolution's input is the output of the block before, a = relu(scale_q * yq + shift_q + x), which no
+// launch has made yet: it is evaluated where the rows arrive (from yq and x, two loads instead of one), rounded to bf16
+// as the stored tensor is, written out by the lanes and strips that own the position, and convolved -- what
+// uh_bn_res_relu_apply followed by the plain walk computes, bit for bit, without reading a back.
+struct DwfApply {
+  const char* yq;
+  int cs, co;
+  const float *scale, *shift;
+  char* a;
+  int a_cs, a_co;
+};
+
+template <int R, bool APPLY>
 __global__ __launch_bounds__(256) void dwconv_fwd_strip_kernel(
     long long Mp, int C, int Wp, int Hp, long long waves, int nsx, int wps, const char* __restrict__ x, int x_cs, int x_co,
     const float* __restrict__ wt, int c_real, const float* __restrict__ bias, char* __restrict__ out, int o_cs, int o_co,
-    float* __restrict__ partial) {
+    float* __restrict__ partial, DwfApply ap) {
   const int ncg = C / 4;
   const int lane = threadIdx.x & 63;
   const int xi = lane >> 2;
@@ -1131,13 +1144,28 @@ __global__ __launch_bounds__(256) void dwconv_fwd_strip_kernel(
   const int nr = left < R ? left : R;
   const char* xp = x + ((((r0 - 1) * Wp + xcol) * x_cs + x_co + c0) * 2);
   const long long x_row = (long long)x_cs * 2 * Wp;
-  auto fetch = [&](int e, U2& t) {
-    t = *(const U2*)xp;
+  const char* yqp = APPLY ? ap.yq + ((((r0 - 1) * Wp + xcol) * ap.cs + ap.co + c0) * 2) : nullptr;
+  const long long yq_row = APPLY ? (long long)ap.cs * 2 * Wp : 0;
+  U2 rawq[DWS_PF] = {};
+  auto fetch = [&](int e, int slot, U2 (&rx)[DWS_PF], U2 (&rq)[DWS_PF]) {
+    rx[slot] = *(const U2*)xp;
     xp += (e <= left) ? x_row : 0;
+    if constexpr (APPLY) {
+      rq[slot] = *(const U2*)yqp;
+      yqp += (e <= left) ? yq_row : 0;
+    }
   };
   U2 raw[DWS_PF];
 #pragma unroll
-  for (int e = 0; e < DWS_PF; ++e) fetch(e, raw[e]);
+  for (int e = 0; e < DWS_PF; ++e) fetch(e, e, raw, rawq);
+  float qsc[4], qsh[4];
+  char* aptr = APPLY ? ap.a + ((((r0 - 1) * Wp + xcol) * ap.a_cs + ap.a_co + c0) * 2) : nullptr;
+  const long long a_row = APPLY ? (long long)ap.a_cs * 2 * Wp : 0;
+  if constexpr (APPLY) {
+    const float4 s4 = *(const float4*)(ap.scale + c0), h4 = *(const float4*)(ap.shift + c0);
+    qsc[0] = s4.x; qsc[1] = s4.y; qsc[2] = s4.z; qsc[3] = s4.w;
+    qsh[0] = h4.x; qsh[1] = h4.y; qsh[2] = h4.z; qsh[3] = h4.w;
+  }
   float w[9][4], b[4], acc[2][4];
   if (c0 + 4 <= c_real) {
     const float4* wp4 = (const float4*)(wt + c0 * 9);
@@ -1178,7 +1206,22 @@ __global__ __launch_bounds__(256) void dwconv_fwd_strip_kernel(
     ry_u = ry_u + 1 == Hp ? 0 : ry_u + 1;
     float c[4], nl[4], nr4[4];
     unpack4(raw[S0], c);
-    if constexpr (decltype(with_fetch)::value) fetch(e + DWS_PF, raw[S0]);
+    if constexpr (APPLY) {
+      float vq[4];
+      unpack4h(rawq[S0], vq);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float t = fmaxf(vq[j] * qsc[j] + qsh[j] + c[j], 0.f);
+        c[j] = ok ? t : 0.f;
+      }
+      U2 av;
+      av.x = pack2(c[0], c[1]);
+      av.y = pack2(c[2], c[3]);
+      unpack4(av, c);                                         // the convolution sees the values as they are stored
+      if (core & (e >= 1) & (e <= nr)) *(U2*)aptr = av;
+      aptr += a_row;
+    }
+    if constexpr (decltype(with_fetch)::value) fetch(e + DWS_PF, S0, raw, rawq);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       nl[j] = lane_read(left_lane, c[j]);
@@ -1253,14 +1296,39 @@ extern "C" int uh_dwconv3x3_fwd_parts(int B, int H, int W, int C) {
 
 static int dwconv_fwd_strip_launch(int B, int H, int W, int C, const void* x, int x_cstride, int x_coff, const float* w,
                                    int c_real, const float* bias, void* out, int o_cstride, int o_coff, float* partial,
-                                   uh_stream s) {
+                                   uh_stream s, const DwfApply* ap) {
   UH_REQUIRE(x_cstride % 4 == 0 && x_coff % 4 == 0 && o_cstride % 4 == 0 && o_coff % 4 == 0, "dwconv3x3_fwd: bad views");
   const DwsGeo g = dws_geo(B, H, W, C);
   UH_REQUIRE(g.strips * g.nsx < (1ll << 31) && (g.waves + 3) / 4 + 8 < (1ll << 31), "dwconv3x3_fwd: %lld waves", g.waves);
-  hipLaunchKernelGGL(dwconv_fwd_strip_kernel<DWS_R>, dim3((unsigned)(((g.waves + 3) / 4 + 7) / 8 * 8)), dim3(256), 0,
+  auto* kern = ap ? dwconv_fwd_strip_kernel<DWS_R, true> : dwconv_fwd_strip_kernel<DWS_R, false>;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(((g.waves + 3) / 4 + 7) / 8 * 8)), dim3(256), 0,
                      (hipStream_t)s, uh_mp(B, H, W), C, W + 1, H + 1, g.waves, g.nsx, g.wps, (const char*)x, x_cstride,
-                     x_coff, w, c_real, bias, (char*)out, o_cstride, o_coff, partial);
+                     x_coff, w, c_real, bias, (char*)out, o_cstride, o_coff, partial, ap ? *ap : DwfApply{});
   return uh_check_launch("dwconv3x3_fwd");
+}
+
+// 1 when uh_dwconv3x3_fwd_applied can be called for C channels (the strip walk is in use), else 0
+extern "C" int uh_dwconv3x3_fwd_takes_apply(int C) { return dwf_use_strip(C) ? 1 : 0; }
+
+// The training forward of the SECOND block of a pair: its input a = relu(scale_q * yq + shift_q + xq) (the first block's
+// BatchNorm + residual + ReLU, uh_bn_res_relu_apply) is made here, written to `a`, and convolved:
+// out = fp16(dwconv3x3(a) + bias), partial[uh_dwconv3x3_fwd_parts][2][C] = (sum, sum of squares).  Same bits as the two
+// launches it replaces.
+extern "C" int uh_dwconv3x3_fwd_applied(int B, int H, int W, int C, const void* yq, int yq_cstride, int yq_coff,
+                                        const void* xq, int xq_cstride, int xq_coff, const float* scale_q,
+                                        const float* shift_q, void* a, int a_cstride, int a_coff, const float* w,
+                                        int c_real, const float* bias, void* out, int o_cstride, int o_coff,
+                                        float* partial, uh_stream s) {
+  EW_CHECK("dwconv3x3_fwd_applied", C);
+  UH_REQUIRE(B > 0 && H > 0 && W > 0 && yq && xq && scale_q && shift_q && a && w && out && partial,
+             "dwconv3x3_fwd_applied: bad arguments");
+  UH_REQUIRE(dwf_use_strip(C), "dwconv3x3_fwd_applied: C=%d needs the strip walk (a power of two in [8, 512], "
+             "UNET_AMD_DWFWD_TILES unset)", C);
+  UH_REQUIRE(c_real > 0 && c_real <= C && ((uintptr_t)w & 15) == 0, "dwconv3x3_fwd_applied: c_real=%d of C=%d, w 16-byte aligned", c_real, C);
+  UH_REQUIRE(yq_cstride % 4 == 0 && yq_coff % 4 == 0 && a_cstride % 4 == 0 && a_coff % 4 == 0 && a != xq && a != out,
+             "dwconv3x3_fwd_applied: bad views");
+  const DwfApply ap{(const char*)yq, yq_cstride, yq_coff, scale_q, shift_q, (char*)a, a_cstride, a_coff};
+  return dwconv_fwd_strip_launch(B, H, W, C, xq, xq_cstride, xq_coff, w, c_real, bias, out, o_cstride, o_coff, partial, s, &ap);
 }
 
 // UNET_AMD_DWBLOCK_LDS=1: the workgroup kernel with the LDS exchange instead of the strip walk.  Read at every call

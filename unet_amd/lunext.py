@@ -30,6 +30,9 @@ FUSED_DW_BWD = os.environ.get("UNET_AMD_LUNEXT_FUSED_DW", "1") == "1"
 # UNET_AMD_LUNEXT_PAIR_SUMS=0: the first block of a pair makes its BatchNorm-backward sums in a pass of its own
 # (uh_bn_res_relu_bwd_reduce) instead of getting them from the second block's backward (uh_dwblock_bwd_prev).
 PAIR_SUMS = os.environ.get("UNET_AMD_LUNEXT_PAIR_SUMS", "1") == "1"
+# UNET_AMD_LUNEXT_PAIR_APPLY=0: the first block of a pair writes its output in a launch of its own
+# (uh_bn_res_relu_apply) instead of leaving it to the second block's convolution (uh_dwconv3x3_fwd_applied).
+PAIR_APPLY = os.environ.get("UNET_AMD_LUNEXT_PAIR_APPLY", "1") == "1"
 
 
 def _padc(c):
@@ -84,6 +87,7 @@ class LUNeXtRun:
         self.saved = {}
         self._side_used = None
         self._bn_sums = {}
+        self._pending = {}
         self.packer = lunext_packer_for(module, x.device)       # bf16 GEMM operands, one repack launch per direction
         self.wf = None
         # set by a caller that keeps all parameter gradients in one flat buffer (dp.FlatGrads, laid out by
@@ -105,8 +109,11 @@ class LUNeXtRun:
         return t
 
     # ------------------------------------------------------------------ depthwise block
-    @ranged(lambda name, *a: "fwd/" + name)
-    def _dw(self, name, x, lvl):
+    @ranged(lambda name, *a, **k: "fwd/" + name)
+    def _dw(self, name, x, lvl, defer_apply=False):
+        """One DepthwiseConvBlock forward.  defer_apply (training, first block of a pair): the block's output buffer
+        is handed on unwritten and noted in self._pending with the record of what is to be applied; the next _dw call
+        then makes it inside its own convolution launch (uh_dwconv3x3_fwd_applied) instead of reading it back."""
         blk = getattr(self.m, name)
         B, H, W = self.geo[lvl]
         C, Cp = blk.depthwise.out_channels, x.C
@@ -145,15 +152,24 @@ class LUNeXtRun:
                  self.pool.counters(s).data_ptr(), s)
         else:
             stat = Ls.f32(parts * 2 * Cp)
-            call("uh_dwconv3x3_fwd", B, H, W, Cp, x.ptr, x.cstride, x.coff, wt.data_ptr(), C, bias.data_ptr(),
-                 EPI_RAW_STATS, None, None, mask.data_ptr(), rec.y.ptr, rec.y.cstride, rec.y.coff, stat.data_ptr(), s)
+            q = self._pending.pop(id(x), None)
+            if q is not None:                        # x = relu(bn(q.y) + q.x) is made by this launch
+                call("uh_dwconv3x3_fwd_applied", B, H, W, Cp, q.y.ptr, q.y.cstride, q.y.coff, q.x.ptr, q.x.cstride,
+                     q.x.coff, q.scale.data_ptr(), q.shift.data_ptr(), x.ptr, x.cstride, x.coff, wt.data_ptr(), C,
+                     bias.data_ptr(), rec.y.ptr, rec.y.cstride, rec.y.coff, stat.data_ptr(), s)
+            else:
+                call("uh_dwconv3x3_fwd", B, H, W, Cp, x.ptr, x.cstride, x.coff, wt.data_ptr(), C, bias.data_ptr(),
+                     EPI_RAW_STATS, None, None, mask.data_ptr(), rec.y.ptr, rec.y.cstride, rec.y.coff, stat.data_ptr(), s)
             call("uh_bn_finalize", stat.data_ptr(), parts, Cp, C, B * H * W, blk.bn.weight.data_ptr(),
                  blk.bn.bias.data_ptr(), BN_EPS, BN_MOMENTUM, rec.mean.data_ptr(), rec.invstd.data_ptr(),
                  rec.scale.data_ptr(), rec.shift.data_ptr(), blk.bn.running_mean.data_ptr(),
                  blk.bn.running_var.data_ptr(), blk.bn.num_batches_tracked.data_ptr(), s)
+        self.recs[name] = rec
+        if defer_apply and PAIR_APPLY and not fused_finalize() and L.uh_dwconv3x3_fwd_takes_apply(Cp):
+            self._pending[id(a)] = rec
+            return a
         call("uh_bn_res_relu_apply", x.Mp, Cp, rec.y.ptr, rec.y.cstride, rec.y.coff, x.ptr, x.cstride, x.coff,
              rec.scale.data_ptr(), rec.shift.data_ptr(), mask.data_ptr(), a.ptr, a.cstride, a.coff, s)
-        self.recs[name] = rec
         return a
 
     @ranged(lambda name, *a: "bwd/" + name)
@@ -530,15 +546,15 @@ class LUNeXtRun:
         call("uh_nchw_to_c8", B, cin, H, W, self.x.data_ptr(), cur.ptr, cur.cstride, cur.coff, s)
         skips = []
         for l in range(1, 5):                                   # lunext.py:199-216
-            cur = self._dw(f"conv{l}_2", self._dw(f"conv{l}_1", cur, l - 1), l - 1)
+            cur = self._dw(f"conv{l}_2", self._dw(f"conv{l}_1", cur, l - 1, defer_apply=True), l - 1)
             skips.append(cur)
             cur = self._down(l, cur)
-        cur = self._dw("conv5_2", self._dw("conv5_1", cur, 4), 4)
+        cur = self._dw("conv5_2", self._dw("conv5_1", cur, 4, defer_apply=True), 4)
         for k in range(1, 5):                                   # lunext.py:223-254
             l = 4 - k
             up = self._up(k, cur)
             cur = self._gate(k, up, skips[l])
-            cur = self._dw(f"conv_up{k}_2", self._dw(f"conv_up{k}_1", cur, l), l)
+            cur = self._dw(f"conv_up{k}_2", self._dw(f"conv_up{k}_1", cur, l, defer_apply=True), l)
         oc = m.out_channels
         fc = m.final_conv
         w = Ls.f32(oc * 8).view(oc, 8)
@@ -547,6 +563,9 @@ class LUNeXtRun:
         call("uh_head_fwd", B, H, W, 8, oc, cur.ptr, cur.cstride, cur.coff, w.data_ptr(), fc.bias.data_ptr(),
              logits.data_ptr(), s)
         self.head_in, self.head_w = cur, w
+        if self._pending:
+            raise RuntimeError("a depthwise block's output was left to a launch that never ran: " +
+                               ", ".join(r.name for r in self._pending.values()))
         return logits
 
     def backward(self, dlogits, gflat=None):
