@@ -1410,27 +1410,40 @@ extern "C" int uh_dwblock_bwd_prev(int B, int H, int W, int C, const void* da, i
 // partial[P][9][C] -> the module's own weight-gradient layout out[c_real][1][3][3] (padding channels dropped)
 __global__ __launch_bounds__(1024) void dw_wgrad_finalize_kernel(const float* __restrict__ partial, int P, int C,
                                                                  int c_real, float* __restrict__ out) {
-  __shared__ double lds[128 * 8];
-  const int ncol = 9 * C, c0 = blockIdx.x * 8;
-  const int t = threadIdx.x, c8 = t & 7, slot = t >> 3;
+  // A workgroup adds 32 adjacent columns of the table: 32 lanes read 128 contiguous bytes of a row, 32 row slots walk the
+  // rows, eight rows fetched before any is added (the strip-walk backward leaves thousands of rows: a chain of one load
+  // per row and 32-byte pieces took 20-45 us per launch).  Fixed order, double accumulators.
+  __shared__ double lds[32 * 33];
+  const int ncol = 9 * C, c0 = blockIdx.x * 32;
+  const int t = threadIdx.x, cl = t & 31, slot = t >> 5;
+  const int col = c0 + cl;
   double s = 0.0;
-  if (c0 + c8 < ncol)
-    for (int p = slot; p < P; p += 128) s += (double)partial[(long long)p * ncol + c0 + c8];
-  lds[slot * 8 + c8] = s;
-  __syncthreads();
-  for (int stride = 64; stride > 0; stride >>= 1) {
-    if (slot < stride) lds[slot * 8 + c8] += lds[(slot + stride) * 8 + c8];
-    __syncthreads();
+  if (col < ncol) {
+    const float* src = partial + col;
+    int p = slot;
+    for (; p + 7 * 32 < P; p += 8 * 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[(long long)(p + u * 32) * ncol];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (double)v[u];
+    }
+    for (; p < P; p += 32) s += (double)src[(long long)p * ncol];
   }
-  if (t < 8 && c0 + t < ncol) {
+  lds[slot * 33 + cl] = s;
+  __syncthreads();
+  if (t < 32 && c0 + t < ncol) {
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) v += lds[k * 33 + t];
     const int tap = (c0 + t) / C, c = (c0 + t) % C;
-    if (c < c_real) out[c * 9 + tap] = (float)lds[t];
+    if (c < c_real) out[c * 9 + tap] = (float)v;
   }
 }
 
 extern "C" int uh_dw_wgrad_finalize(const float* partial, int P, int C, int c_real, float* out, uh_stream s) {
   UH_REQUIRE(partial && out && P > 0 && C > 0 && c_real > 0 && c_real <= C, "dw_wgrad_finalize: bad arguments");
-  hipLaunchKernelGGL(dw_wgrad_finalize_kernel, dim3((9 * C + 7) / 8), dim3(1024), 0, (hipStream_t)s, partial, P, C,
+  hipLaunchKernelGGL(dw_wgrad_finalize_kernel, dim3((9 * C + 31) / 32), dim3(1024), 0, (hipStream_t)s, partial, P, C,
                      c_real, out);
   return uh_check_launch("dw_wgrad_finalize");
 }
