@@ -329,6 +329,14 @@ int uh_gate_fwd(long long Mp, int C, const void* z, int z_cstride, int z_coff, c
 int uh_gate_bwd(long long Mp, int C, const void* dout, int d_cstride, int d_coff, const void* z, int z_cstride,
                 int z_coff, const void* x, int x_cstride, int x_coff, const uint8_t* rowmask,
                 void* dz, int dz_cstride, int dz_coff, void* dxd, int dx_cstride, int dx_coff, uh_stream s);
+/* uh_gate_bwd that also takes the column sums of dz as it stores it (the gradients of the biases of the gate's three
+ * 1x1 convolutions, lunext.py:88-95): partial[uh_gate_bwd_parts(Mp, C)][3 * C] for
+ * uh_colsum_finalize(partial, parts, 3 * C, ...), in place of a uh_colsum pass over the 3C-channel tensor. */
+int uh_gate_bwd_parts(long long Mp, int C);
+int uh_gate_bwd_colsum(long long Mp, int C, const void* dout, int d_cstride, int d_coff, const void* z, int z_cstride,
+                       int z_coff, const void* x, int x_cstride, int x_coff, const uint8_t* rowmask,
+                       void* dz, int dz_cstride, int dz_coff, void* dxd, int dx_cstride, int dx_coff,
+                       float* partial, uh_stream s);
 /* out = a + b (+ c when c != null) */
 int uh_add(long long Mp, int C, const void* a, int a_cstride, int a_coff, const void* b, int b_cstride, int b_coff,
            const void* c, int c_cstride, int c_coff, void* out, int o_cstride, int o_coff, uh_stream s);

@@ -1054,6 +1054,20 @@ def test_gate_pointwise_forward_backward(B, H, W, C):
     close(dxd.to_nchw(), xt.grad, 1e-2, "gate backward: the direct path to x")
     pads_are_zero(dz)
     pads_are_zero(dxd)
+    # the same launch with the column sums of dz (the three bias gradients): same tensors, sums of the stored values
+    dz2, dxd2 = new_act(B, H, W, 3 * C, DEV), new_act(B, H, W, C, DEV)
+    parts = lib.uh_gate_bwd_parts(za.Mp, C)
+    assert parts >= 1
+    part = torch.full((parts, 3 * C), float("nan"), device=DEV)
+    call("uh_gate_bwd_colsum", za.Mp, C, da.ptr, da.cstride, da.coff, za.ptr, za.cstride, 0, xa.ptr, xa.cstride, xa.coff,
+         rowmask(B, H, W).data_ptr(), dz2.ptr, dz2.cstride, 0, dxd2.ptr, dxd2.cstride, dxd2.coff, part.data_ptr(), S())
+    db = torch.empty(3 * C, device=DEV)
+    call("uh_colsum_finalize", part.data_ptr(), parts, 3 * C, 1, db.data_ptr(), 0, S())
+    torch.cuda.synchronize()
+    assert torch.equal(dz.buf, dz2.buf) and torch.equal(dxd.buf, dxd2.buf)
+    stored = dz.to_nchw().double()
+    torch.testing.assert_close(db.double().cpu(), stored.sum((0, 2, 3)).cpu(), rtol=1e-5,
+                               atol=1e-5 * stored.abs().sum((0, 2, 3)).max().item())
 
 
 @pytest.mark.parametrize("B,H,W,C", [(2, 16, 16, 3), (1, 8, 12, 2), (3, 4, 4, 8)])

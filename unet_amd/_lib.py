@@ -93,6 +93,8 @@ SIGNATURES = {
     "uh_dwblock_bwd_prev": (I, [I, I, I, I, P, I, I, P, I, I, P, I, I, P, I, P, P, P, P, P, P, I, I, P, P, I, I, P, P, P, P]),
     "uh_gate_fwd": (I, [L, I, P, I, I, P, I, I, P, I, I, P]),
     "uh_gate_bwd": (I, [L, I, P, I, I, P, I, I, P, I, I, P, P, I, I, P, I, I, P]),
+    "uh_gate_bwd_parts": (I, [L, I]),
+    "uh_gate_bwd_colsum": (I, [L, I, P, I, I, P, I, I, P, I, I, P, P, I, I, P, I, I, P, P]),
     "uh_add": (I, [L, I, P, I, I, P, I, I, P, I, I, P, I, I, P]),
     "uh_gate8_fwd": (I, [L, I, P, I, I, P, I, I, P, P, P, I, I, P]),
     "uh_gate8_parts": (I, [L]),

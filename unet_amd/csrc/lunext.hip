@@ -1481,39 +1481,61 @@ extern "C" int uh_gate_fwd(long long Mp, int C, const void* z, int z_cstride, in
 }
 
 // dz1 = dout*c*b*(1-b), dz2 = dout*b*(1-c^2), dz3 = dout*x*a*(1-a), dxd = dout*a
+// SUMS: also the column sums of dz as stored (the gradients of the gate's three biases, lunext.py:88-95), one
+// partial row [3][C] per workgroup for uh_colsum_finalize: the pass that would read the 3C-channel tensor again is
+// the largest of the step's column-sum launches (92 us at 64 channels, 128 x 128, batch 32).
+template <bool SUMS>
 __global__ __launch_bounds__(256) void gate_bwd_kernel(long long Mp, int C, const char* __restrict__ dout, int d_cs,
                                                        int d_co, const char* __restrict__ z, int z_cs, int z_co,
                                                        const char* __restrict__ x, int x_cs, int x_co,
                                                        const uint8_t* __restrict__ rowmask, char* __restrict__ dz,
                                                        int dz_cs, int dz_co, char* __restrict__ dxd, int dx_cs,
-                                                       int dx_co) {
+                                                       int dx_co, float* __restrict__ partial) {
+  extern __shared__ float lds[];
   const int cpr = C / 8, rpi = 256 / cpr;
   const int rr = threadIdx.x / cpr, cc = threadIdx.x % cpr;
-  if (rr >= rpi) return;
-  for (long long m = (long long)blockIdx.x * rpi + rr; m < Mp; m += (long long)gridDim.x * rpi) {
-    float z1[8], z2[8], z3[8], xv[8], g[8], o1[8], o2[8], o3[8], ox[8];
-    const bool on = rowmask[m];
-    const char* zr = z + (m * z_cs + z_co + cc * 8) * 2;
-    unpack8(*(const U4*)zr, z1);
-    unpack8(*(const U4*)(zr + C * 2), z2);
-    unpack8(*(const U4*)(zr + C * 4), z3);
-    unpack8(*(const U4*)(x + (m * x_cs + x_co + cc * 8) * 2), xv);
-    unpack8(*(const U4*)(dout + (m * d_cs + d_co + cc * 8) * 2), g);
+  float acc[3][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float b = sigmoidf_(z1[j]), c = tanhf(z2[j]), a = sigmoidf_(z3[j]);
-      const float d = on ? g[j] : 0.f;
-      o1[j] = d * c * b * (1.f - b);
-      o2[j] = d * b * (1.f - c * c);
-      o3[j] = d * xv[j] * a * (1.f - a);
-      ox[j] = d * a;
+  for (int j = 0; j < 8; ++j) acc[0][j] = acc[1][j] = acc[2][j] = 0.f;
+  if (rr < rpi) {
+    for (long long m = (long long)blockIdx.x * rpi + rr; m < Mp; m += (long long)gridDim.x * rpi) {
+      float z1[8], z2[8], z3[8], xv[8], g[8], o1[8], o2[8], o3[8], ox[8];
+      const bool on = rowmask[m];
+      const char* zr = z + (m * z_cs + z_co + cc * 8) * 2;
+      unpack8(*(const U4*)zr, z1);
+      unpack8(*(const U4*)(zr + C * 2), z2);
+      unpack8(*(const U4*)(zr + C * 4), z3);
+      unpack8(*(const U4*)(x + (m * x_cs + x_co + cc * 8) * 2), xv);
+      unpack8(*(const U4*)(dout + (m * d_cs + d_co + cc * 8) * 2), g);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float b = sigmoidf_(z1[j]), c = tanhf(z2[j]), a = sigmoidf_(z3[j]);
+        const float d = on ? g[j] : 0.f;
+        o1[j] = d * c * b * (1.f - b);
+        o2[j] = d * b * (1.f - c * c);
+        o3[j] = d * xv[j] * a * (1.f - a);
+        ox[j] = d * a;
+      }
+      char* dr = dz + (m * dz_cs + dz_co + cc * 8) * 2;
+      const U4 p1 = pack8(o1), p2 = pack8(o2), p3 = pack8(o3);
+      *(U4*)dr = p1;
+      *(U4*)(dr + C * 2) = p2;
+      *(U4*)(dr + C * 4) = p3;
+      *(U4*)(dxd + (m * dx_cs + dx_co + cc * 8) * 2) = pack8(ox);
+      if (SUMS) {
+        unpack8(p1, o1);
+        unpack8(p2, o2);
+        unpack8(p3, o3);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          acc[0][j] += o1[j];
+          acc[1][j] += o2[j];
+          acc[2][j] += o3[j];
+        }
+      }
     }
-    char* dr = dz + (m * dz_cs + dz_co + cc * 8) * 2;
-    *(U4*)dr = pack8(o1);
-    *(U4*)(dr + C * 2) = pack8(o2);
-    *(U4*)(dr + C * 4) = pack8(o3);
-    *(U4*)(dxd + (m * dx_cs + dx_co + cc * 8) * 2) = pack8(ox);
   }
+  if (SUMS) block_combine_store<3>(acc, C, cpr, rpi, lds, partial + (long long)blockIdx.x * 3 * C);
 }
 
 extern "C" int uh_gate_bwd(long long Mp, int C, const void* dout, int d_cstride, int d_coff, const void* z,
@@ -1522,10 +1544,28 @@ extern "C" int uh_gate_bwd(long long Mp, int C, const void* dout, int d_cstride,
                            int dx_coff, uh_stream s) {
   EW_CHECK("gate_bwd", C);
   UH_REQUIRE(Mp > 0 && dout && z && x && rowmask && dz && dxd, "gate_bwd: bad arguments");
-  hipLaunchKernelGGL(gate_bwd_kernel, dim3(ew_blocks(Mp, C)), dim3(256), 0, (hipStream_t)s, Mp, C, (const char*)dout,
-                     d_cstride, d_coff, (const char*)z, z_cstride, z_coff, (const char*)x, x_cstride, x_coff, rowmask,
-                     (char*)dz, dz_cstride, dz_coff, (char*)dxd, dx_cstride, dx_coff);
+  hipLaunchKernelGGL(gate_bwd_kernel<false>, dim3(ew_blocks(Mp, C)), dim3(256), 0, (hipStream_t)s, Mp, C,
+                     (const char*)dout, d_cstride, d_coff, (const char*)z, z_cstride, z_coff, (const char*)x, x_cstride,
+                     x_coff, rowmask, (char*)dz, dz_cstride, dz_coff, (char*)dxd, dx_cstride, dx_coff, nullptr);
   return uh_check_launch("gate_bwd");
+}
+
+// uh_gate_bwd that also leaves the column sums of dz: partial[uh_gate_bwd_parts(Mp, C)][3 * C], for
+// uh_colsum_finalize(partial, parts, 3 * C, ...)
+extern "C" int uh_gate_bwd_parts(long long Mp, int C) { return (C > 0 && C % 8 == 0 && C / 8 <= 256) ? ew_stat_blocks(Mp, C) : 0; }
+
+extern "C" int uh_gate_bwd_colsum(long long Mp, int C, const void* dout, int d_cstride, int d_coff, const void* z,
+                                  int z_cstride, int z_coff, const void* x, int x_cstride, int x_coff,
+                                  const uint8_t* rowmask, void* dz, int dz_cstride, int dz_coff, void* dxd,
+                                  int dx_cstride, int dx_coff, float* partial, uh_stream s) {
+  EW_CHECK("gate_bwd_colsum", C);
+  UH_REQUIRE(Mp > 0 && dout && z && x && rowmask && dz && dxd && partial, "gate_bwd_colsum: bad arguments");
+  const int rpi = ew_rows_per_iter(C);
+  hipLaunchKernelGGL(gate_bwd_kernel<true>, dim3(ew_stat_blocks(Mp, C)), dim3(256), (size_t)rpi * 3 * C * 4,
+                     (hipStream_t)s, Mp, C, (const char*)dout, d_cstride, d_coff, (const char*)z, z_cstride, z_coff,
+                     (const char*)x, x_cstride, x_coff, rowmask, (char*)dz, dz_cstride, dz_coff, (char*)dxd, dx_cstride,
+                     dx_coff, partial);
+  return uh_check_launch("gate_bwd_colsum");
 }
 
 // out = a + b (+ c)

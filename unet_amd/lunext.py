@@ -489,8 +489,11 @@ class LUNeXtRun:
         g, x, ssum, z = self.saved[f"att{k}"]
         mask = self.masks[l]
         dz, dxd = Ls.act(B, H, W, 3 * C), Ls.act(B, H, W, C)
-        call("uh_gate_bwd", g.Mp, C, dout.ptr, dout.cstride, dout.coff, z.ptr, z.cstride, 0, x.ptr, x.cstride, x.coff,
-             mask.data_ptr(), dz.ptr, dz.cstride, 0, dxd.ptr, dxd.cstride, dxd.coff, s)
+        # the three bias gradients are the column sums of dz: taken by the launch that writes it
+        bparts = L.uh_gate_bwd_parts(g.Mp, C)
+        bpart = Ls.f32(bparts * 3 * C)
+        call("uh_gate_bwd_colsum", g.Mp, C, dout.ptr, dout.cstride, dout.coff, z.ptr, z.cstride, 0, x.ptr, x.cstride,
+             x.coff, mask.data_ptr(), dz.ptr, dz.cstride, 0, dxd.ptr, dxd.cstride, dxd.coff, bpart.data_ptr(), s)
         # bias and weight gradients only read dz, g and g + x: on the second stream, beside the input gradients below
         # (weight gradients: [dW1; dW2] = dz[:, :2C]^T g,  dW3 = dz[:, 2C:]^T (g + x))
         S = L.uh_conv_wgrad_splits(B, H, W, 2 * C, C, 1)
@@ -501,8 +504,9 @@ class LUNeXtRun:
         dws = [self._gnew(pre + nm + ".weight", (C, C, 1, 1)) for nm in names]
         with self._side() as s2:
             # in a flat gradient buffer the three biases lie side by side (flat_param_order)
-            db = self._colsum(dz, 3 * C, s2, out=None if self.gflat is None else
-                              self.gflat.span(pre + "sigmoid_conv.bias", 3 * C))
+            db = (torch.empty(3 * C, dtype=torch.float32, device=self.device) if self.gflat is None else
+                  self.gflat.span(pre + "sigmoid_conv.bias", 3 * C))
+            call("uh_colsum_finalize", bpart.data_ptr(), bparts, 3 * C, 1, db.data_ptr(), 0, s2)
             call("uh_conv_wgrad", B, H, W, dz.ptr, dz.cstride, 0, 2 * C, g.ptr, g.cstride, g.coff, C, 1,
                  part.data_ptr(), s2)
             for j in range(2):
