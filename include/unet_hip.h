@@ -362,6 +362,15 @@ int uh_dwblock_bwd(int B, int H, int W, int C, const void* da, int da_cstride, i
  * statistics.  uh_dwblock_bwd_takes_prev() is 1 when the kernel in use can do this (0 under
  * UNET_AMD_DWBLOCK_LDS=1, and uh_dwblock_bwd_prev then returns an error). */
 int uh_dwblock_bwd_takes_prev(void);
+/* uh_dwblock_bwd for the first block behind a 2x2 stride-2 convolution (lunext.py:139-154): dx is that convolution's
+ * output gradient, whose column sums are its bias gradient.  They are taken from dx as it is stored:
+ * colsum[uh_dwblock_bwd_parts][C] for uh_colsum_finalize(colsum, parts, C, ...), in place of a uh_colsum pass.
+ * Available when uh_dwblock_bwd_takes_prev() is 1. */
+int uh_dwblock_bwd_colsum(int B, int H, int W, int C, const void* da, int da_cstride, int da_coff,
+                          const void* y, int y_cstride, int y_coff, const void* x, int x_cstride, int x_coff,
+                          const float* w, int c_real,
+                          const float* mean, const float* invstd, const float* scale, const float* shift, const float* coef,
+                          void* dx, int dx_cstride, int dx_coff, float* partial, float* colsum, uh_stream s);
 int uh_dwblock_bwd_prev(int B, int H, int W, int C, const void* da, int da_cstride, int da_coff,
                         const void* y, int y_cstride, int y_coff, const void* x, int x_cstride, int x_coff,
                         const float* w, int c_real,

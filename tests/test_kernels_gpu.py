@@ -948,6 +948,20 @@ def test_depthwise_block_backward_leaves_the_previous_block_its_sums(B, H, W, C,
     assert ((b1 - b0).abs() <= 2e-5 * mag0).all(), "dbeta"
     assert ((g1 - g0).abs() <= 2e-5 * mag1).all(), "dgamma"
     assert ((c1 - c0)[:, :c_real].abs() <= 2e-5 * torch.stack([mag0, mag1]) / (B * H * W) + 1e-9).all(), "coef"
+    # and the variant that leaves the column sums of dx (the bias gradient of a convolution in front of the block)
+    dx2 = new_act(B, H, W, C, DEV)
+    wp2 = torch.empty(parts, 9, C, device=DEV)
+    cpart = torch.full((parts, C), float("nan"), device=DEV)
+    call("uh_dwblock_bwd_colsum", B, H, W, C, daa.ptr, daa.cstride, daa.coff, ya.ptr, ya.cstride, ya.coff, xa.ptr,
+         xa.cstride, xa.coff, wt.data_ptr(), c_real, *stp, coef.data_ptr(), dx2.ptr, dx2.cstride, dx2.coff,
+         wp2.data_ptr(), cpart.data_ptr(), S())
+    db = torch.empty(C, device=DEV)
+    call("uh_colsum_finalize", cpart.data_ptr(), parts, C, 1, db.data_ptr(), 0, S())
+    torch.cuda.synchronize()
+    assert torch.equal(dx0.buf, dx2.buf) and torch.equal(wp0, wp2)
+    stored = dx0.to_nchw().double()
+    torch.testing.assert_close(db.double().cpu(), stored.sum((0, 2, 3)).cpu(), rtol=1e-5,
+                               atol=2e-6 * stored.abs().sum((0, 2, 3)).max().item() + 1e-6)
 
 
 @pytest.mark.parametrize("B,H,W,C,OC", [(2, 8, 12, 64, 1), (1, 5, 7, 64, 2), (2, 16, 16, 8, 1)])

@@ -90,6 +90,7 @@ SIGNATURES = {
     "uh_dwconv3x3_fwd_applied": (I, [I, I, I, I, P, I, I, P, I, I, P, P, P, I, I, P, I, P, P, I, I, P, P]),
     "uh_dwblock_bwd": (I, [I, I, I, I, P, I, I, P, I, I, P, I, I, P, I, P, P, P, P, P, P, I, I, P, P]),
     "uh_dwblock_bwd_takes_prev": (I, []),
+    "uh_dwblock_bwd_colsum": (I, [I, I, I, I, P, I, I, P, I, I, P, I, I, P, I, P, P, P, P, P, P, I, I, P, P, P]),
     "uh_dwblock_bwd_prev": (I, [I, I, I, I, P, I, I, P, I, I, P, I, I, P, I, P, P, P, P, P, P, I, I, P, P, I, I, P, P, P, P]),
     "uh_gate_fwd": (I, [L, I, P, I, I, P, I, I, P, I, I, P]),
     "uh_gate_bwd": (I, [L, I, P, I, I, P, I, I, P, I, I, P, P, I, I, P, I, I, P]),

@@ -871,13 +871,15 @@ struct DwsPrev {
   float* partial;       // [strips * column blocks][2][C]
 };
 
-template <int R, bool PREV>
+// COLS: also the column sums of dx as stored (dx is the output gradient of the 2x2 stride-2 convolution in front of
+// the block: its bias gradient, lunext.py:139-154) in colsum[strips * column blocks][C], for uh_colsum_finalize.
+template <int R, bool PREV, bool COLS>
 __global__ __launch_bounds__(256) void dwblock_bwd_strip_kernel(
     long long Mp, int C, int Wp, int Hp, long long waves, int nsx, int wps, const char* __restrict__ da, int da_cs,
     int da_co, const char* __restrict__ y, int y_cs, int y_co, const char* __restrict__ x, int x_cs, int x_co,
     const float* __restrict__ wt, int c_real, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ coef,
-    char* __restrict__ dx, int dx_cs, int dx_co, float* __restrict__ partial, DwsPrev pv) {
+    char* __restrict__ dx, int dx_cs, int dx_co, float* __restrict__ partial, DwsPrev pv, float* __restrict__ colsum) {
   const int ncg = C / 4;
   const int lane = threadIdx.x & 63;
   const int xi = lane >> 2;
@@ -943,7 +945,7 @@ __global__ __launch_bounds__(256) void dwblock_bwd_strip_kernel(
   const char* yqp = PREV ? pv.yq + (((r0 * Wp + xcol) * pv.cs + pv.co + c0) * 2) : nullptr;
   const long long yq_row = PREV ? (long long)pv.cs * 2 * Wp : 0;
   U2 rawq[3] = {};
-  float qs[2][4], qmu[4], qis[4];
+  float qs[2][4], qmu[4], qis[4], cs[1][4] = {{0.f, 0.f, 0.f, 0.f}};
   if constexpr (PREV) {
     const float4 m4 = *(const float4*)(pv.mean + c0), i4 = *(const float4*)(pv.invstd + c0);
     qmu[0] = m4.x; qmu[1] = m4.y; qmu[2] = m4.z; qmu[3] = m4.w;
@@ -1051,8 +1053,15 @@ __global__ __launch_bounds__(256) void dwblock_bwd_strip_kernel(
     U2 ov;
     ov.x = pack2(o[0], o[1]);
     ov.y = pack2(o[2], o[3]);
-    if (core & (e >= 3) & (e - 2 <= nr)) *(U2*)op = ov;
+    const bool st = core & (e >= 3) & (e - 2 <= nr);
+    if (st) *(U2*)op = ov;
     op += orow;
+    if constexpr (COLS) {
+      float dr[4];
+      unpack4(ov, dr);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) cs[0][j] += st ? dr[j] : 0.f;
+    }
     if constexpr (PREV) {
       // xr of the stored row is the block input where this lane stores and 0 elsewhere (other lanes' columns, other
       // strips' rows, padding): exactly the positions whose dx counts, once
@@ -1096,6 +1105,7 @@ __global__ __launch_bounds__(256) void dwblock_bwd_strip_kernel(
   step(std::integral_constant<int, 2>{}, No{}, R + 2);
   dws_store_row<9>(acc, lane, live, ncg, nsx, strip, sx, C, c0, partial);
   if constexpr (PREV) dws_store_row<2>(qs, lane, live, ncg, nsx, strip, sx, C, c0, pv.partial);
+  if constexpr (COLS) dws_store_row<1>(cs, lane, live, ncg, nsx, strip, sx, C, c0, colsum);
 }
 
 // ---- the depthwise forward of a training step as the same kind of walk ------------------------------------------------
@@ -1351,7 +1361,7 @@ static int dwblock_bwd_launch(const char* what, int B, int H, int W, int C, cons
                               const void* y, int y_cstride, int y_coff, const void* x, int x_cstride, int x_coff,
                               const float* w, int c_real, const float* mean, const float* invstd, const float* scale,
                               const float* shift, const float* coef, void* dx, int dx_cstride, int dx_coff,
-                              float* partial, const DwsPrev* pv, uh_stream s) {
+                              float* partial, const DwsPrev* pv, float* colsum, uh_stream s) {
   UH_REQUIRE(B > 0 && H > 0 && W > 0 && da && y && x && w && mean && invstd && scale && shift && coef && dx && partial,
              "%s: bad arguments", what);
   UH_REQUIRE(C >= 8 && C <= 512 && (C & (C - 1)) == 0, "%s: C=%d must be a power of two in [8,512]", what, C);
@@ -1362,14 +1372,16 @@ static int dwblock_bwd_launch(const char* what, int B, int H, int W, int C, cons
   if (dwb_use_strip()) {
     const DwsGeo g = dws_geo(B, H, W, C);
     UH_REQUIRE(g.strips * g.nsx < (1ll << 31) && (g.waves + 3) / 4 + 8 < (1ll << 31), "%s: %lld waves", what, g.waves);
-    auto* kern = pv ? dwblock_bwd_strip_kernel<DWS_R, true> : dwblock_bwd_strip_kernel<DWS_R, false>;
+    UH_REQUIRE(!(pv && colsum), "%s: one extra output at a time", what);
+    auto* kern = pv ? dwblock_bwd_strip_kernel<DWS_R, true, false>
+                    : colsum ? dwblock_bwd_strip_kernel<DWS_R, false, true> : dwblock_bwd_strip_kernel<DWS_R, false, false>;
     hipLaunchKernelGGL(kern, dim3((unsigned)(((g.waves + 3) / 4 + 7) / 8 * 8)), dim3(256), 0, (hipStream_t)s, Mp, C,
                        W + 1, H + 1, g.waves, g.nsx, g.wps, (const char*)da, da_cstride, da_coff, (const char*)y, y_cstride,
                        y_coff, (const char*)x, x_cstride, x_coff, w, c_real, mean, invstd, scale, shift, coef, (char*)dx,
-                       dx_cstride, dx_coff, partial, pv ? *pv : DwsPrev{});
+                       dx_cstride, dx_coff, partial, pv ? *pv : DwsPrev{}, colsum);
     return uh_check_launch(what);
   }
-  UH_REQUIRE(!pv, "%s: only the strip walk takes the previous block's sums (UNET_AMD_DWBLOCK_LDS is set)", what);
+  UH_REQUIRE(!pv && !colsum, "%s: only the strip walk takes further sums (UNET_AMD_DWBLOCK_LDS is set)", what);
   const int xt = 256 / (C / 4);
   hipLaunchKernelGGL(dwblock_bwd_kernel, dwb_grid(B, H, W, C), dim3(256), (size_t)xt * 9 * C * 4, (hipStream_t)s, Mp, C,
                      W + 1, H + 1, (const char*)da, da_cstride, da_coff, (const char*)y, y_cstride, y_coff,
@@ -1384,7 +1396,20 @@ extern "C" int uh_dwblock_bwd(int B, int H, int W, int C, const void* da, int da
                               const float* shift, const float* coef, void* dx, int dx_cstride, int dx_coff,
                               float* partial, uh_stream s) {
   return dwblock_bwd_launch("dwblock_bwd", B, H, W, C, da, da_cstride, da_coff, y, y_cstride, y_coff, x, x_cstride, x_coff,
-                            w, c_real, mean, invstd, scale, shift, coef, dx, dx_cstride, dx_coff, partial, nullptr, s);
+                            w, c_real, mean, invstd, scale, shift, coef, dx, dx_cstride, dx_coff, partial, nullptr, nullptr, s);
+}
+
+// uh_dwblock_bwd that also leaves the column sums of dx as stored: colsum[uh_dwblock_bwd_parts][C], for
+// uh_colsum_finalize(colsum, parts, C, ...).  Available when uh_dwblock_bwd_takes_prev() is 1.
+extern "C" int uh_dwblock_bwd_colsum(int B, int H, int W, int C, const void* da, int da_cstride, int da_coff,
+                                     const void* y, int y_cstride, int y_coff, const void* x, int x_cstride, int x_coff,
+                                     const float* w, int c_real, const float* mean, const float* invstd,
+                                     const float* scale, const float* shift, const float* coef, void* dx,
+                                     int dx_cstride, int dx_coff, float* partial, float* colsum, uh_stream s) {
+  UH_REQUIRE(colsum, "dwblock_bwd_colsum: bad arguments");
+  return dwblock_bwd_launch("dwblock_bwd_colsum", B, H, W, C, da, da_cstride, da_coff, y, y_cstride, y_coff, x, x_cstride,
+                            x_coff, w, c_real, mean, invstd, scale, shift, coef, dx, dx_cstride, dx_coff, partial, nullptr,
+                            colsum, s);
 }
 
 // 1 when uh_dwblock_bwd_prev can be called (the strip walk is in use), else 0
@@ -1404,7 +1429,7 @@ extern "C" int uh_dwblock_bwd_prev(int B, int H, int W, int C, const void* da, i
              "dwblock_bwd_prev: bad arguments");
   const DwsPrev pv{(const char*)yq, yq_cstride, yq_coff, mean_q, invstd_q, prev_partial};
   return dwblock_bwd_launch("dwblock_bwd_prev", B, H, W, C, da, da_cstride, da_coff, y, y_cstride, y_coff, x, x_cstride,
-                            x_coff, w, c_real, mean, invstd, scale, shift, coef, dx, dx_cstride, dx_coff, partial, &pv, s);
+                            x_coff, w, c_real, mean, invstd, scale, shift, coef, dx, dx_cstride, dx_coff, partial, &pv, nullptr, s);
 }
 
 // partial[P][9][C] -> the module's own weight-gradient layout out[c_real][1][3][3] (padding channels dropped)

@@ -88,6 +88,7 @@ class LUNeXtRun:
         self._side_used = None
         self._bn_sums = {}
         self._pending = {}
+        self._dx_colsum = {}
         self.packer = lunext_packer_for(module, x.device)       # bf16 GEMM operands, one repack launch per direction
         self.wf = None
         # set by a caller that keeps all parameter gradients in one flat buffer (dp.FlatGrads, laid out by
@@ -173,10 +174,11 @@ class LUNeXtRun:
         return a
 
     @ranged(lambda name, *a: "bwd/" + name)
-    def _dw_backward(self, name, da, grads, prev=None):
+    def _dw_backward(self, name, da, grads, prev=None, colsum=False):
         """`prev`: name of the depthwise block whose output is this block's input and is read by nothing else (the
         first block of a pair).  Its BatchNorm-backward sums are then taken while this block's input gradient is
-        stored (uh_dwblock_bwd_prev), and its own _dw_backward call finds them in self._bn_sums."""
+        stored (uh_dwblock_bwd_prev), and its own _dw_backward call finds them in self._bn_sums.
+        `colsum`: the returned gradient goes to _down_backward, which wants its column sums."""
         rec = self.recs[name]
         B, H, W = self.geo[rec.lvl]
         C, Cp, x, y = rec.C, rec.Cp, rec.x, rec.y
@@ -221,6 +223,14 @@ class LUNeXtRun:
                      dx.coff, wp.data_ptr(), q.y.ptr, q.y.cstride, q.y.coff, q.mean.data_ptr(), q.invstd.data_ptr(),
                      qpart.data_ptr(), s)
                 self._bn_sums[prev] = (qpart, wparts)
+            elif colsum and PAIR_SUMS and L.uh_dwblock_bwd_takes_prev():
+                # dx is the output gradient of the convolution in front of the block: its column sums (that
+                # convolution's bias gradient) are taken here, _down_backward finds them in self._dx_colsum
+                cpart = Ls.f32(wparts * Cp)
+                call("uh_dwblock_bwd_colsum", B, H, W, Cp, da.ptr, da.cstride, da.coff, y.ptr, y.cstride, y.coff, x.ptr,
+                     x.cstride, x.coff, rec.wt.data_ptr(), C, *st, coef.data_ptr(), dx.ptr, dx.cstride,
+                     dx.coff, wp.data_ptr(), cpart.data_ptr(), s)
+                self._dx_colsum[id(dx)] = (cpart, wparts)
             else:
                 call("uh_dwblock_bwd", B, H, W, Cp, da.ptr, da.cstride, da.coff, y.ptr, y.cstride, y.coff, x.ptr,
                      x.cstride, x.coff, rec.wt.data_ptr(), C, *st, coef.data_ptr(), dx.ptr, dx.cstride,
@@ -277,7 +287,13 @@ class LUNeXtRun:
         part = Ls.f32(S * cout * K)
         dw = self._gnew(f"downconv{l}.weight", conv.weight.shape)
         with self._side() as s2:
-            grads[f"downconv{l}.bias"] = self._colsum(dy, cout, s2, out=self._gnew(f"downconv{l}.bias", (cout,)))
+            ready = self._dx_colsum.pop(id(dy), None)
+            if ready is not None:                     # the launch that wrote dy has left its column sums behind
+                db = self._gnew(f"downconv{l}.bias", (cout,))
+                call("uh_colsum_finalize", ready[0].data_ptr(), ready[1], cout, 1, db.data_ptr(), 0, s2)
+                grads[f"downconv{l}.bias"] = db
+            else:
+                grads[f"downconv{l}.bias"] = self._colsum(dy, cout, s2, out=self._gnew(f"downconv{l}.bias", (cout,)))
             call("uh_conv_wgrad", Bs, Hs, Ws, dy.ptr, dy.cstride, dy.coff, cout, x4.ptr, x4.cstride, 0, K, 1,
                  part.data_ptr(), s2)
             call("uh_wgrad_reduce_strided", part.data_ptr(), S, cout * K, cout, 4, cin, K, cpi, cin * 4, 1, 4,
@@ -612,12 +628,13 @@ class LUNeXtRun:
             dg, dx = self._gate_backward(k, da, grads)
             skip_grads[l] = dx
             da = self._up_backward(k, dg, grads)
-        da = self._dw_backward("conv5_1", self._dw_backward("conv5_2", da, grads, prev="conv5_1"), grads)
+        da = self._dw_backward("conv5_1", self._dw_backward("conv5_2", da, grads, prev="conv5_1"), grads, colsum=True)
         for l in range(4, 0, -1):
             if (l - 1) in self._skip_ready:
                 self._main.wait_event(self._skip_ready[l - 1])
             tot = self._down_backward(l, da, grads, skip_grads[l - 1])
-            da = self._dw_backward(f"conv{l}_1", self._dw_backward(f"conv{l}_2", tot, grads, prev=f"conv{l}_1"), grads)
+            da = self._dw_backward(f"conv{l}_1", self._dw_backward(f"conv{l}_2", tot, grads, prev=f"conv{l}_1"), grads,
+                                   colsum=l > 1)
         if self._side_used is not None:
             self._main.wait_stream(self._side_used)
         return grads
