@@ -9,6 +9,8 @@ would take minutes per case: size-independent properties instead of element-wise
     bf16/fp32 rounding), forward and input-gradient mode, at a full-size layer shape;
   * train-mode BatchNorm identity: the gradient of a conv bias in front of BatchNorm is exactly 0, and every other
     parameter receives a finite, non-zero gradient;
+  * the depthwise block's strip-walk kernels (forward and backward) give the bits of the kernels they replace at the
+    LUNeXt level shapes of batch 32 (thousands of strips, every column block);
   * soft-skeleton order relations: erode(x) <= x <= dilate(x), 0 <= skel <= 1, skel(mask) supported on the mask,
     loss of a prediction equal to the (binary) target < loss of its complement.
 """
@@ -228,3 +230,45 @@ def test_unet_large_images(b, hw):
     counts = torch.zeros(4, dtype=torch.int64, device=DEV)
     trainer.confusion_counts(full, m, counts)
     assert counts.sum().item() == b * hw * hw
+
+
+@pytest.mark.parametrize("H,C,c_real", [(256, 8, 3), (128, 64, 64), (32, 256, 256)])
+def test_depthwise_strip_walks_give_the_column_kernels_bits_at_full_size(H, C, c_real, monkeypatch):
+    """LUNeXt level shapes at batch 32: uh_dwconv3x3_fwd (training) and uh_dwblock_bwd as per-wave strip walks against
+    the one-thread-per-column kernels (UNET_AMD_DWFWD_TILES=1, UNET_AMD_DWBLOCK_LDS=1): y and dx bit for bit, the
+    reduced sums to summation order."""
+    g = torch.Generator(device=DEV).manual_seed(H + C)
+    live = (torch.arange(C, device=DEV) < c_real).float().view(1, C, 1, 1)
+    rnd = lambda: torch.randn(B, C, H, H, generator=g, device=DEV) * live          # noqa: E731
+    x, da, y = new_act(B, H, H, C, DEV), new_act(B, H, H, C, DEV), new_act(B, H, H, C, DEV)
+    x.fill_from_nchw(rnd())
+    da.fill_from_nchw(rnd())
+    y.fill_from_nchw(rnd() * 1.5, half=True)
+    wt = torch.randn(c_real, 1, 3, 3, generator=g, device=DEV) / 3
+    bias = torch.randn(c_real, generator=g, device=DEV)
+    st = [torch.randn(C, generator=g, device=DEV) * 0.2, torch.rand(C, generator=g, device=DEV) + 0.5,
+          torch.randn(C, generator=g, device=DEV) * live.view(-1), torch.randn(C, generator=g, device=DEV) * 0.3 * live.view(-1)]
+    coef = torch.randn(2, C, generator=g, device=DEV) * 0.05
+    mask = pool_for(DEV).rowmask(B, H, H)
+    outs = {}
+    for mode in ("strip", "column"):
+        if mode == "column":
+            monkeypatch.setenv("UNET_AMD_DWFWD_TILES", "1")
+            monkeypatch.setenv("UNET_AMD_DWBLOCK_LDS", "1")
+        fp, bp = lib.uh_dwconv3x3_fwd_parts(B, H, H, C), lib.uh_dwblock_bwd_parts(B, H, H, C)
+        yo, dx = new_act(B, H, H, C, DEV), new_act(B, H, H, C, DEV)
+        stat, wp = torch.empty(fp, 2, C, device=DEV), torch.empty(bp, 9, C, device=DEV)
+        call("uh_dwconv3x3_fwd", B, H, H, C, x.ptr, x.cstride, x.coff, wt.data_ptr(), c_real, bias.data_ptr(),
+             _lib.EPI_RAW_STATS, None, None, mask.data_ptr(), yo.ptr, yo.cstride, yo.coff, stat.data_ptr(), S())
+        call("uh_dwblock_bwd", B, H, H, C, da.ptr, da.cstride, da.coff, y.ptr, y.cstride, y.coff, x.ptr, x.cstride,
+             x.coff, wt.data_ptr(), c_real, *[t.data_ptr() for t in st], coef.data_ptr(), dx.ptr, dx.cstride, dx.coff,
+             wp.data_ptr(), S())
+        dw = torch.empty(c_real, 1, 3, 3, device=DEV)
+        call("uh_dw_wgrad_finalize", wp.data_ptr(), bp, C, c_real, dw.data_ptr(), S())
+        torch.cuda.synchronize()
+        outs[mode] = (yo, dx, stat.double().sum(0), dw)
+    (y0, dx0, s0, dw0), (y1, dx1, s1, dw1) = outs["strip"], outs["column"]
+    assert torch.equal(y0.buf, y1.buf), "forward"
+    assert torch.equal(dx0.buf, dx1.buf), "input gradient"
+    torch.testing.assert_close(s0, s1, rtol=1e-6, atol=1e-3)
+    torch.testing.assert_close(dw0, dw1, rtol=1e-4, atol=1e-4 * dw1.abs().max().item())
