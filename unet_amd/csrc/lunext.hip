@@ -828,7 +828,10 @@ __device__ __forceinline__ void dws_store_row(float (&v)[N][4], int lane, bool l
         const float o = lane_read((lane + sh8) * 4, a);
         a += (lane + sh8 < 64) ? o : 0.f;
       }
-      if (ncg == 2) a += lane_read((lane + 2) * 4, a);      // (read by lanes 0 and 1 only: lanes 2 and 3 exist)
+      // (lanes 0 and 1 use it, lanes 2 and 3 exist.  A select, not a branch: with a branch here the compiler no longer
+      //  pairs the callers' multiply-adds into packed instructions in their main loops, 118 -> 75 v_pk_fma_f32)
+      const float o2 = lane_read((lane + 2) * 4, a);
+      a += ncg == 2 ? o2 : 0.f;
       v[k][j] = a;
     }
   const bool writer = live & (lane < (ncg == 2 ? 2 : 4));
