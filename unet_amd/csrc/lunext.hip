@@ -807,39 +807,83 @@ __global__ __launch_bounds__(256) void dwblock_bwd_kernel(
 // one per (strip, column block) instead of one per workgroup.
 #define DWS_CORE 14
 #define DWS_PF 3      // a row's loads are issued this many steps before its use
+// Two channels of a lane side by side: the multiply-adds below are written on pairs so that they are v_pk_fma_f32
+// (two FMAs per lane and issue) whatever the compiler's own pairing of scalar code would have found.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 sel2(bool k, f2 a) { return k ? a : (f2){0.f, 0.f}; }
 __device__ __forceinline__ float lane_read(int byte_addr, float v) {          // v of lane byte_addr / 4
   return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_addr, __builtin_bit_cast(int, v)));
 }
 // Per-lane sums v[N][4] (N quantities x this lane's four channels; lanes that own nothing hold zeros) -> one row of
-// table[rows][N][C]: the 16 columns of a pair are added in a fixed order; with two channel groups (C = 8) the wave's two
-// column blocks as well, so that the table has one row per strip and PAIR of column blocks (half as many rows for the
-// finalisation launch to add up, which is a chain of loads per row).
+// table[rows][N][C].  The 16 columns of a pair are added by a butterfly that halves what a lane holds at every stage
+// (lanes with the stage's bit clear keep the first half of their values and take the partner's first half, the others
+// the second): 4N values cost about 4N lane reads instead of 16N, and the tail is a seventh of a wave's instructions
+// otherwise.  Fixed order.  With two channel groups (C = 8) the wave's two column blocks are added as well, so that the
+// table has one row per strip and PAIR of column blocks (half as many rows for the finalisation launch to add up, which
+// is a chain of loads per row).
 __host__ __device__ __forceinline__ int dws_rows_per_strip(int nsx, int ncg) { return ncg == 2 ? (nsx + 1) / 2 : nsx; }
 template <int N>
 __device__ __forceinline__ void dws_store_row(float (&v)[N][4], int lane, bool live, int ncg, int nsx, long long strip,
                                               int sx, int C, int c0, float* __restrict__ table) {
+  if constexpr (N <= 2) {
+    // few values: the plain tree (every value over the 16 columns, lanes 0..3 end up with the totals); the butterfly's
+    // bookkeeping would cost the forward kernel its 128th register and with it a wave per SIMD
 #pragma unroll
-  for (int k = 0; k < N; ++k)
+    for (int k = 0; k < N; ++k)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float a = v[k][j];
+      for (int j = 0; j < 4; ++j) {
+        float a = v[k][j];
 #pragma unroll
-      for (int sh8 = 32; sh8 >= 4; sh8 >>= 1) {
-        const float o = lane_read((lane + sh8) * 4, a);
-        a += (lane + sh8 < 64) ? o : 0.f;
+        for (int sh8 = 32; sh8 >= 4; sh8 >>= 1) {
+          const float o = lane_read((lane + sh8) * 4, a);
+          a += (lane + sh8 < 64) ? o : 0.f;
+        }
+        const float o2 = lane_read((lane + 2) * 4, a);
+        a += ncg == 2 ? o2 : 0.f;
+        v[k][j] = a;
       }
-      // (lanes 0 and 1 use it, lanes 2 and 3 exist.  A select, not a branch: with a branch here the compiler no longer
-      //  pairs the callers' multiply-adds into packed instructions in their main loops, 118 -> 75 v_pk_fma_f32)
-      const float o2 = lane_read((lane + 2) * 4, a);
-      a += ncg == 2 ? o2 : 0.f;
-      v[k][j] = a;
-    }
-  const bool writer = live & (lane < (ncg == 2 ? 2 : 4));
-  if (writer) {
-    const long long row = ncg == 2 ? strip * ((nsx + 1) / 2) + (sx >> 1) : strip * nsx + sx;
-    float* dst = table + (row * N) * C + c0;
+    if (live & (lane < (ncg == 2 ? 2 : 4))) {
+      const long long row = ncg == 2 ? strip * ((nsx + 1) / 2) + (sx >> 1) : strip * nsx + sx;
+      float* dst = table + (row * N) * C + c0;
 #pragma unroll
-    for (int k = 0; k < N; ++k) *(float4*)(dst + (long long)k * C) = make_float4(v[k][0], v[k][1], v[k][2], v[k][3]);
+      for (int k = 0; k < N; ++k) *(float4*)(dst + (long long)k * C) = make_float4(v[k][0], v[k][1], v[k][2], v[k][3]);
+    }
+    return;
+  }
+  constexpr int N4 = N * 4, NP = (N4 + 15) / 16 * 16, F = NP / 16;
+  float a[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) a[i] = i < N4 ? v[i / 4][i % 4] : 0.f;
+  int base = 0;                                               // a[i] is the sum of value base + i
+#pragma unroll
+  for (int st = 0; st < 4; ++st) {                            // lane bits 5, 4, 3, 2: the column index
+    const int half = NP >> (st + 1);
+    const int bit = 5 - st;
+    const bool up = (lane >> bit) & 1;
+    const int partner = (lane ^ (1 << bit)) * 4;
+#pragma unroll
+    for (int i = 0; i < half; ++i) {
+      const float send = up ? a[i] : a[half + i];
+      const float keep = up ? a[half + i] : a[i];
+      a[i] = keep + lane_read(partner, send);
+    }
+    base += up ? half : 0;
+  }
+  // (selects, not branches, up to here: with a branch in this tail the compiler once stopped pairing the callers'
+  //  multiply-adds into packed instructions in their main loops)
+#pragma unroll
+  for (int i = 0; i < F; ++i) {
+    const float o2 = lane_read((lane + 2) * 4, a[i]);         // lanes 0 and 1 of a column use it; lanes 2 and 3 exist
+    a[i] += ncg == 2 ? o2 : 0.f;
+  }
+  const bool writer = live & ((lane & 3) < (ncg == 2 ? 2 : 4));
+  const long long row = ncg == 2 ? strip * ((nsx + 1) / 2) + (sx >> 1) : strip * nsx + sx;
+  float* dst = table + (row * N) * C + c0;
+#pragma unroll
+  for (int i = 0; i < F; ++i) {
+    const int idx = base + i;
+    if (writer & (idx < N4)) dst[(long long)(idx >> 2) * C + (idx & 3)] = a[i];
   }
 }
 
@@ -904,6 +948,7 @@ __global__ __launch_bounds__(256) void dwblock_bwd_strip_kernel(
   const bool core = live & (xi >= 1) & (xi <= DWS_CORE) & (xcol < Wp);  // columns this lane writes (pad column included)
   const bool col_in = live & (xcol >= 0) & (xcol < Wp - 1);   // an interior column of the images
   float acc[9][4], w[9][4], sc[4], sh[4], bp[4], cq[4];
+  f2 sc2[2], sh2[2], bp2[2], cq2[2];
   // step e (0 .. R + 2) meets tensor row r0 - 1 + e.  The row before the first strip is a guard row (zeros, and
   // counts as a pad row); past the last row the walk stays on the first row after the end (a guard row as well) and
   // everything there counts as padding.  All of this is the same for the whole wave.
@@ -926,19 +971,20 @@ __global__ __launch_bounds__(256) void dwblock_bwd_strip_kernel(
     yp += in ? y_row : 0;
     xp += in ? x_row : 0;
   };
-  auto eval = [&](const DwbRaw& t, bool keep, float (&dyv)[4], float (&dc)[4], float (&xc)[4]) {
+  // (pairs of channels, [h] = channels 2h and 2h + 1 of the lane's four: see fma2)
+  auto eval = [&](const DwbRaw& t, bool keep, f2 (&dyv)[2], f2 (&dc)[2], f2 (&xc)[2]) {
     float gf[4], vf[4], xf[4];
     unpack4(t.g, gf);
     unpack4h(t.v, vf);
     unpack4(t.r, xf);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const bool on = keep & (vf[j] * sc[j] + sh[j] + xf[j] > 0.f);
-      const float d = on ? gf[j] : 0.f;
-      dc[j] = d;
-      xc[j] = keep ? xf[j] : 0.f;
-      const float qv = fmaf(sc[j], d, -fmaf(vf[j], cq[j], bp[j]));
-      dyv[j] = keep ? qv : 0.f;
+    for (int h = 0; h < 2; ++h) {
+      const f2 g2 = {gf[2 * h], gf[2 * h + 1]}, v2 = {vf[2 * h], vf[2 * h + 1]}, x2 = {xf[2 * h], xf[2 * h + 1]};
+      const f2 pre = fma2(v2, sc2[h], sh2[h]) + x2;
+      const f2 d = {(keep & (pre.x > 0.f)) ? g2.x : 0.f, (keep & (pre.y > 0.f)) ? g2.y : 0.f};
+      dc[h] = d;
+      xc[h] = sel2(keep, x2);
+      dyv[h] = sel2(keep, fma2(sc2[h], d, -fma2(v2, cq2[h], bp2[h])));
     }
   };
   DwbRaw raw[DWS_PF];
@@ -987,18 +1033,30 @@ __global__ __launch_bounds__(256) void dwblock_bwd_strip_kernel(
       sh[j] = h_[j];
       cq[j] = sc[j] * b_[j] * i_[j];
       bp[j] = sc[j] * a_[j] - cq[j] * m_[j];
+    }
 #pragma unroll
-      for (int t = 0; t < 9; ++t) acc[t][j] = 0.f;
+    for (int h = 0; h < 2; ++h) {
+      sc2[h] = (f2){sc[2 * h], sc[2 * h + 1]};
+      sh2[h] = (f2){sh[2 * h], sh[2 * h + 1]};
+      cq2[h] = (f2){cq[2 * h], cq[2 * h + 1]};
+      bp2[h] = (f2){bp[2 * h], bp[2 * h + 1]};
     }
   }
-  float xr[3][4];                                             // block input of the rows of steps e - 2, e - 1, e (mod 3)
-  float part_a[4], part_b[4];                                 // output rows e - 2 (top and middle taps in) and e - 1 (top taps in)
-  float hc[4], hd[4], hl[4], hr[4];                           // row of step e - 1: dy and centre term at this column, dy left, dy right
+  f2 xr[3][2];                                                // block input of the rows of steps e - 2, e - 1, e (mod 3)
+  f2 part_a[2], part_b[2];                                    // output rows e - 2 (top and middle taps in) and e - 1 (top taps in)
+  f2 hc[2], hd[2], hl[2], hr[2];                              // row of step e - 1: dy and centre term at this column, dy left, dy right
+  f2 acc2[9][2], w2[9][2];
   bool ok_a = false, ok_h = false;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    xr[0][j] = xr[1][j] = xr[2][j] = 0.f;
-    part_a[j] = part_b[j] = hc[j] = hd[j] = hl[j] = hr[j] = 0.f;
+  for (int h = 0; h < 2; ++h) {
+    const f2 z = {0.f, 0.f};
+    xr[0][h] = xr[1][h] = xr[2][h] = z;
+    part_a[h] = part_b[h] = hc[h] = hd[h] = hl[h] = hr[h] = z;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      acc2[t][h] = z;
+      w2[t][h] = (f2){w[t][2 * h], w[t][2 * h + 1]};
+    }
   }
   char* op = dx + (((r0 - 3) * Wp + xcol) * dx_cs + dx_co + c0) * 2;         // step e finishes the row of step e - 2
   const long long orow = (long long)dx_cs * 2 * Wp;
@@ -1013,49 +1071,49 @@ __global__ __launch_bounds__(256) void dwblock_bwd_strip_kernel(
     const bool row_ok = (e <= left) & (ry_u != Hp - 1) & (e <= R + 1);
     ry_u = ry_u + 1 == Hp ? 0 : ry_u + 1;
     const bool ok = row_ok & col_in;
-    float c[4], dc[4], xc[4], nl[4], nr4[4];
+    f2 c[2], dc[2], xc[2], nl[2], nr2[2];
     eval(raw[S0], ok, c, dc, xc);
     if constexpr (decltype(with_fetch)::value) fetch(e + DWS_PF, raw[S0]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      nl[j] = lane_read(left_lane, c[j]);                     // (the first and last column of the wave read some other
-      nr4[j] = lane_read(right_lane, c[j]);                   //  lane: their taps are incomplete anyway, see `core`)
+    for (int h = 0; h < 2; ++h) {                             // (the first and last column of the wave read some other
+      nl[h] = (f2){lane_read(left_lane, c[h].x), lane_read(left_lane, c[h].y)};      // lane: their taps are incomplete
+      nr2[h] = (f2){lane_read(right_lane, c[h].x), lane_read(right_lane, c[h].y)};   // anyway, see `core`)
     }
-    const bool own_row = (e >= 1) & (e <= R);             // only the strip's own rows add their block input
+    const bool own_row = (e >= 1) & (e <= R);                 // only the strip's own rows add their block input
 #pragma unroll
-    for (int j = 0; j < 4; ++j) xr[S0][j] = (core & own_row) ? xc[j] : 0.f;
+    for (int h = 0; h < 2; ++h) xr[S0][h] = sel2(core & own_row, xc[h]);
     // ---- second half: the row of step e - 1 (tap d of a row pairs with the column x + 1 - d)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      acc[0][j] = fmaf(xr[S2][j], hr[j], acc[0][j]);
-      acc[1][j] = fmaf(xr[S2][j], hc[j], acc[1][j]);
-      acc[2][j] = fmaf(xr[S2][j], hl[j], acc[2][j]);
-      acc[3][j] = fmaf(xr[S1][j], hr[j], acc[3][j]);
-      acc[4][j] = fmaf(xr[S1][j], hc[j], acc[4][j]);
-      acc[5][j] = fmaf(xr[S1][j], hl[j], acc[5][j]);
-      acc[6][j] = fmaf(xr[S0][j], hr[j], acc[6][j]);
-      acc[7][j] = fmaf(xr[S0][j], hc[j], acc[7][j]);
-      acc[8][j] = fmaf(xr[S0][j], hl[j], acc[8][j]);
+    for (int h = 0; h < 2; ++h) {
+      acc2[0][h] = fma2(xr[S2][h], hr[h], acc2[0][h]);
+      acc2[1][h] = fma2(xr[S2][h], hc[h], acc2[1][h]);
+      acc2[2][h] = fma2(xr[S2][h], hl[h], acc2[2][h]);
+      acc2[3][h] = fma2(xr[S1][h], hr[h], acc2[3][h]);
+      acc2[4][h] = fma2(xr[S1][h], hc[h], acc2[4][h]);
+      acc2[5][h] = fma2(xr[S1][h], hl[h], acc2[5][h]);
+      acc2[6][h] = fma2(xr[S0][h], hr[h], acc2[6][h]);
+      acc2[7][h] = fma2(xr[S0][h], hc[h], acc2[7][h]);
+      acc2[8][h] = fma2(xr[S0][h], hl[h], acc2[8][h]);
     }
-    float o[4];
+    f2 o[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float v = part_a[j];                                    // the bottom taps finish output row e - 2
-      v = fmaf(hr[j], w[0][j], v);
-      v = fmaf(hc[j], w[1][j], v);
-      v = fmaf(hl[j], w[2][j], v);
-      o[j] = ok_a ? v : 0.f;                                  // (the window around a pad position holds real neighbours)
-      v = part_b[j] + hd[j];                                  // centre term and middle taps: output row e - 1
-      v = fmaf(hr[j], w[3][j], v);
-      v = fmaf(hc[j], w[4][j], v);
-      part_a[j] = fmaf(hl[j], w[5][j], v);
-      float t = fmaf(hr[j], w[6][j], 0.f);                    // top taps: output row e starts
-      t = fmaf(hc[j], w[7][j], t);
-      part_b[j] = fmaf(hl[j], w[8][j], t);
+    for (int h = 0; h < 2; ++h) {
+      f2 v = part_a[h];                                       // the bottom taps finish output row e - 2
+      v = fma2(hr[h], w2[0][h], v);
+      v = fma2(hc[h], w2[1][h], v);
+      v = fma2(hl[h], w2[2][h], v);
+      o[h] = sel2(ok_a, v);                                   // (the window around a pad position holds real neighbours)
+      v = part_b[h] + hd[h];                                  // centre term and middle taps: output row e - 1
+      v = fma2(hr[h], w2[3][h], v);
+      v = fma2(hc[h], w2[4][h], v);
+      part_a[h] = fma2(hl[h], w2[5][h], v);
+      f2 t = fma2(hr[h], w2[6][h], (f2){0.f, 0.f});           // top taps: output row e starts
+      t = fma2(hc[h], w2[7][h], t);
+      part_b[h] = fma2(hl[h], w2[8][h], t);
     }
     U2 ov;
-    ov.x = pack2(o[0], o[1]);
-    ov.y = pack2(o[2], o[3]);
+    ov.x = pack2(o[0].x, o[0].y);
+    ov.y = pack2(o[1].x, o[1].y);
     const bool st = core & (e >= 3) & (e - 2 <= nr);
     if (st) *(U2*)op = ov;
     op += orow;
@@ -1073,7 +1131,7 @@ __global__ __launch_bounds__(256) void dwblock_bwd_strip_kernel(
       unpack4h(rawq[S2], vq);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float d = xr[S2][j] > 0.f ? dr[j] : 0.f;
+        const float d = xr[S2][j >> 1][j & 1] > 0.f ? dr[j] : 0.f;
         qs[0][j] += d;
         qs[1][j] += d * (vq[j] - qmu[j]) * qis[j];
       }
@@ -1085,11 +1143,11 @@ __global__ __launch_bounds__(256) void dwblock_bwd_strip_kernel(
     ok_a = ok_h;
     ok_h = ok;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      hc[j] = c[j];
-      hd[j] = dc[j];
-      hl[j] = nl[j];
-      hr[j] = nr4[j];
+    for (int h = 0; h < 2; ++h) {
+      hc[h] = c[h];
+      hd[h] = dc[h];
+      hl[h] = nl[h];
+      hr[h] = nr2[h];
     }
   };
   static_assert(R % 3 == 0 && DWS_PF == 3, "the rings are walked three steps at a time");
@@ -1106,6 +1164,13 @@ __global__ __launch_bounds__(256) void dwblock_bwd_strip_kernel(
   step(std::integral_constant<int, 0>{}, No{}, R);
   step(std::integral_constant<int, 1>{}, No{}, R + 1);
   step(std::integral_constant<int, 2>{}, No{}, R + 2);
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      acc[t][2 * h] = acc2[t][h].x;
+      acc[t][2 * h + 1] = acc2[t][h].y;
+    }
   dws_store_row<9>(acc, lane, live, ncg, nsx, strip, sx, C, c0, partial);
   if constexpr (PREV) dws_store_row<2>(qs, lane, live, ncg, nsx, strip, sx, C, c0, pv.partial);
   if constexpr (COLS) dws_store_row<1>(cs, lane, live, ncg, nsx, strip, sx, C, c0, colsum);
@@ -1207,10 +1272,19 @@ __global__ __launch_bounds__(256) void dwconv_fwd_strip_kernel(
     acc[0][j] = acc[1][j] = 0.f;
   }
   int ry_u = (int)((r0 + Hp - 1) % Hp);                       // image row of the row the next step meets
-  float part_a[4], part_b[4], hc[4], hl[4], hr[4];            // output rows e - 2 and e - 1 so far; x of the row of step e - 1
+  // pairs of channels from here on: [h] = channels 2h, 2h + 1 of the lane's four
+  f2 w2[9][2], b2[2], acc2[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) w2[t][h] = (f2){w[t][2 * h], w[t][2 * h + 1]};
+    b2[h] = (f2){b[2 * h], b[2 * h + 1]};
+    acc2[0][h] = acc2[1][h] = (f2){0.f, 0.f};
+  }
+  f2 part_a[2], part_b[2], hc[2], hl[2], hr[2];               // output rows e - 2 and e - 1 so far; x of the row of step e - 1
   bool ok_a = false, ok_h = false;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) part_a[j] = part_b[j] = hc[j] = hl[j] = hr[j] = 0.f;
+  for (int h = 0; h < 2; ++h) part_a[h] = part_b[h] = hc[h] = hl[h] = hr[h] = (f2){0.f, 0.f};
   char* op = out + (((r0 - 3) * Wp + xcol) * o_cs + o_co + c0) * 2;          // step e finishes the row of step e - 2
   const long long orow = (long long)o_cs * 2 * Wp;
   auto step = [&](auto ph, auto with_fetch, int e) {
@@ -1240,38 +1314,38 @@ __global__ __launch_bounds__(256) void dwconv_fwd_strip_kernel(
       nl[j] = lane_read(left_lane, c[j]);
       nr4[j] = lane_read(right_lane, c[j]);
     }
-    float v[4];
+    f2 v[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float t = part_a[j];                                    // the bottom taps finish output row e - 2
-      t = fmaf(hl[j], w[6][j], t);
-      t = fmaf(hc[j], w[7][j], t);
-      t = fmaf(hr[j], w[8][j], t);
-      v[j] = ok_a ? t : 0.f;
-      t = part_b[j];                                          // middle taps: output row e - 1
-      t = fmaf(hl[j], w[3][j], t);
-      t = fmaf(hc[j], w[4][j], t);
-      part_a[j] = fmaf(hr[j], w[5][j], t);
-      t = fmaf(hl[j], w[0][j], b[j]);                         // bias and top taps: output row e starts
-      t = fmaf(hc[j], w[1][j], t);
-      part_b[j] = fmaf(hr[j], w[2][j], t);
+    for (int h = 0; h < 2; ++h) {
+      f2 t = part_a[h];                                       // the bottom taps finish output row e - 2
+      t = fma2(hl[h], w2[6][h], t);
+      t = fma2(hc[h], w2[7][h], t);
+      t = fma2(hr[h], w2[8][h], t);
+      v[h] = sel2(ok_a, t);
+      t = part_b[h];                                          // middle taps: output row e - 1
+      t = fma2(hl[h], w2[3][h], t);
+      t = fma2(hc[h], w2[4][h], t);
+      part_a[h] = fma2(hr[h], w2[5][h], t);
+      t = fma2(hl[h], w2[0][h], b2[h]);                       // bias and top taps: output row e starts
+      t = fma2(hc[h], w2[1][h], t);
+      part_b[h] = fma2(hr[h], w2[2][h], t);
     }
     const bool st = core & (e >= 3) & (e - 2 <= nr);
     if (st) {
       U2 ov;
-      ov.x = pack2h(v[0], v[1]);
-      ov.y = pack2h(v[2], v[3]);
+      ov.x = pack2h(v[0].x, v[0].y);
+      ov.y = pack2h(v[1].x, v[1].y);
       *(U2*)op = ov;
     }
     op += orow;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float u = st ? v[j] : 0.f;
-      acc[0][j] += u;
-      acc[1][j] += u * u;
-      hc[j] = c[j];
-      hl[j] = nl[j];
-      hr[j] = nr4[j];
+    for (int h = 0; h < 2; ++h) {
+      const f2 u = sel2(st, v[h]);
+      acc2[0][h] += u;
+      acc2[1][h] = fma2(u, u, acc2[1][h]);
+      hc[h] = (f2){c[2 * h], c[2 * h + 1]};
+      hl[h] = (f2){nl[2 * h], nl[2 * h + 1]};
+      hr[h] = (f2){nr4[2 * h], nr4[2 * h + 1]};
     }
     ok_a = ok_h;
     ok_h = ok;
@@ -1288,6 +1362,13 @@ __global__ __launch_bounds__(256) void dwconv_fwd_strip_kernel(
   step(std::integral_constant<int, 0>{}, No{}, R);
   step(std::integral_constant<int, 1>{}, No{}, R + 1);
   step(std::integral_constant<int, 2>{}, No{}, R + 2);
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      acc[k][2 * h] = acc2[k][h].x;
+      acc[k][2 * h + 1] = acc2[k][h].y;
+    }
   dws_store_row<2>(acc, lane, live, ncg, nsx, strip, sx, C, c0, partial);
 }
 
