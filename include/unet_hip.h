@@ -343,6 +343,15 @@ int uh_add(long long Mp, int C, const void* a, int a_cstride, int a_coff, const 
 /* weight gradient of the depthwise convolution: the partial[parts][9][C] rows of uh_dwconv3x3_wgrad summed into the
  * module's own layout out[c_real][1][3][3] (lunext.py:14), padding channels dropped */
 int uh_dw_wgrad_finalize(const float* partial, int parts, int C, int c_real, float* out, uh_stream s);
+/* the same for several layers in one launch (a training step has 18 of them, each a few microseconds of work behind a
+ * launch and a stream dependency of its own): descs is a HOST array, copied into the launch's arguments */
+#define UH_DWFIN_MAX 32
+typedef struct {
+  const float* partial;   /* [parts][9][C] */
+  float* out;             /* [c_real][1][3][3] */
+  int parts, C, c_real;
+} uh_dwfin_desc;
+int uh_dw_wgrad_finalize_multi(const uh_dwfin_desc* descs, int count, uh_stream s);
 /* The backward of one DepthwiseConvBlock (lunext.py:6-30) behind its BatchNorm sums, in one pass: what
  * uh_bn_res_relu_bwd_apply + uh_dwconv3x3_dgrad + uh_dwconv3x3_wgrad compute, without storing dy and dr
  * (dy is used in fp32, not rounded to bf16).  coef is uh_bn_bwd_finalize's output; partial[parts][9][C] goes to

@@ -1042,6 +1042,25 @@ def test_space_to_depth_of_odd_sizes(B, h, w, bigH, bigW, C):
     pads_are_zero(back)
 
 
+def test_depthwise_weight_gradient_tables_added_up_in_one_launch():
+    """uh_dw_wgrad_finalize_multi against one uh_dw_wgrad_finalize per table: the same bits."""
+    g = torch.Generator().manual_seed(97)
+    shapes = [(37, 8, 3), (2300, 64, 64), (1, 16, 16), (513, 128, 128), (64, 512, 512)]
+    tabs = [torch.randn(p, 9, c, generator=g).to(DEV) for p, c, _ in shapes]
+    one = [torch.empty(cr, 1, 3, 3, device=DEV) for _, _, cr in shapes]
+    many = [torch.full((cr, 1, 3, 3), float("nan"), device=DEV) for _, _, cr in shapes]
+    for t, o, (p, c, cr) in zip(tabs, one, shapes):
+        call("uh_dw_wgrad_finalize", t.data_ptr(), p, c, cr, o.data_ptr(), S())
+    descs = (_lib.DwFinDesc * len(shapes))(*[_lib.DwFinDesc(t.data_ptr(), o.data_ptr(), p, c, cr)
+                                             for t, o, (p, c, cr) in zip(tabs, many, shapes)])
+    call("uh_dw_wgrad_finalize_multi", descs, len(shapes), S())
+    torch.cuda.synchronize()
+    for a, b in zip(one, many):
+        assert torch.equal(a, b)
+    with pytest.raises(RuntimeError):
+        call("uh_dw_wgrad_finalize_multi", descs, _lib.DWFIN_MAX + 1, S())
+
+
 # ---- AttentionGate kernels (lunext.py:76-122) ---------------------------------------------------------------------
 @pytest.mark.parametrize("B,H,W,C", [(2, 8, 8, 64), (1, 6, 10, 128), (2, 4, 4, 256)])
 def test_gate_pointwise_forward_backward(B, H, W, C):

@@ -21,6 +21,13 @@ F = ctypes.c_float
 Z = ctypes.c_size_t
 D = ctypes.c_double
 
+class DwFinDesc(ctypes.Structure):
+    """uh_dwfin_desc: one table of uh_dw_wgrad_finalize_multi"""
+    _fields_ = [("partial", P), ("out", P), ("parts", I), ("C", I), ("c_real", I)]
+
+
+DWFIN_MAX = 32          # UH_DWFIN_MAX
+
 # name -> (restype, argtypes); mirrors include/unet_hip.h one to one
 SIGNATURES = {
     "uh_last_error": (ctypes.c_char_p, []),
@@ -79,6 +86,7 @@ SIGNATURES = {
     "uh_dwconv3x3_dgrad": (I, [I, I, I, I, P, I, I, P, I, P, I, I, P, P, I, I, P]),
     "uh_dwconv3x3_wgrad": (I, [I, I, I, I, P, I, I, P, I, I, P, P]),
     "uh_dw_wgrad_finalize": (I, [P, I, I, I, P, P]),
+    "uh_dw_wgrad_finalize_multi": (I, [P, I, P]),
     "uh_space_to_depth2_of": (I, [I, I, I, I, I, I, P, I, I, P, I, I, P]),
     "uh_depth_to_space2_to": (I, [I, I, I, I, I, I, P, I, I, P, I, I, P]),
     "uh_depth_to_space2_add": (I, [I, I, I, I, I, I, P, I, I, P, I, I, P, I, I, P]),

@@ -1517,13 +1517,12 @@ extern "C" int uh_dwblock_bwd_prev(int B, int H, int W, int C, const void* da, i
 }
 
 // partial[P][9][C] -> the module's own weight-gradient layout out[c_real][1][3][3] (padding channels dropped)
-__global__ __launch_bounds__(1024) void dw_wgrad_finalize_kernel(const float* __restrict__ partial, int P, int C,
-                                                                 int c_real, float* __restrict__ out) {
-  // A workgroup adds 32 adjacent columns of the table: 32 lanes read 128 contiguous bytes of a row, 32 row slots walk the
-  // rows, eight rows fetched before any is added (the strip-walk backward leaves thousands of rows: a chain of one load
-  // per row and 32-byte pieces took 20-45 us per launch).  Fixed order, double accumulators.
-  __shared__ double lds[32 * 33];
-  const int ncol = 9 * C, c0 = blockIdx.x * 32;
+// A workgroup adds 32 adjacent columns of the table: 32 lanes read 128 contiguous bytes of a row, 32 row slots walk the
+// rows, eight rows fetched before any is added (the strip-walk backward leaves thousands of rows: a chain of one load
+// per row and 32-byte pieces took 20-45 us per launch).  Fixed order, double accumulators.
+__device__ __forceinline__ void dw_wgrad_finalize_block(const float* __restrict__ partial, int P, int C, int c_real,
+                                                        float* __restrict__ out, int blk, double* lds /*[32 * 33]*/) {
+  const int ncol = 9 * C, c0 = blk * 32;
   const int t = threadIdx.x, cl = t & 31, slot = t >> 5;
   const int col = c0 + cl;
   double s = 0.0;
@@ -1550,11 +1549,49 @@ __global__ __launch_bounds__(1024) void dw_wgrad_finalize_kernel(const float* __
   }
 }
 
+__global__ __launch_bounds__(1024) void dw_wgrad_finalize_kernel(const float* __restrict__ partial, int P, int C,
+                                                                 int c_real, float* __restrict__ out) {
+  __shared__ double lds[32 * 33];
+  dw_wgrad_finalize_block(partial, P, C, c_real, out, blockIdx.x, lds);
+}
+
 extern "C" int uh_dw_wgrad_finalize(const float* partial, int P, int C, int c_real, float* out, uh_stream s) {
   UH_REQUIRE(partial && out && P > 0 && C > 0 && c_real > 0 && c_real <= C, "dw_wgrad_finalize: bad arguments");
   hipLaunchKernelGGL(dw_wgrad_finalize_kernel, dim3((9 * C + 31) / 32), dim3(1024), 0, (hipStream_t)s, partial, P, C,
                      c_real, out);
   return uh_check_launch("dw_wgrad_finalize");
+}
+
+// the same for up to UH_DWFIN_MAX tables in one launch: the descriptors travel as kernel arguments
+struct DwFinTable {
+  uh_dwfin_desc d[UH_DWFIN_MAX];
+  int first[UH_DWFIN_MAX + 1];      // first workgroup of each table
+  int n;
+};
+__global__ __launch_bounds__(1024) void dw_wgrad_finalize_multi_kernel(DwFinTable t) {
+  __shared__ double lds[32 * 33];
+  int i = 0;
+  while (i + 1 < t.n && (int)blockIdx.x >= t.first[i + 1]) ++i;            // (uniform over the workgroup)
+  const uh_dwfin_desc& d = t.d[i];
+  dw_wgrad_finalize_block(d.partial, d.parts, d.C, d.c_real, d.out, (int)blockIdx.x - t.first[i], lds);
+}
+
+extern "C" int uh_dw_wgrad_finalize_multi(const uh_dwfin_desc* descs, int count, uh_stream s) {
+  UH_REQUIRE(descs && count > 0 && count <= UH_DWFIN_MAX, "dw_wgrad_finalize_multi: 1..%d tables, got %d", UH_DWFIN_MAX, count);
+  DwFinTable t;
+  int blocks = 0;
+  for (int i = 0; i < count; ++i) {
+    const uh_dwfin_desc& d = descs[i];
+    UH_REQUIRE(d.partial && d.out && d.parts > 0 && d.C > 0 && d.c_real > 0 && d.c_real <= d.C,
+               "dw_wgrad_finalize_multi: bad table %d", i);
+    t.d[i] = d;
+    t.first[i] = blocks;
+    blocks += (9 * d.C + 31) / 32;
+  }
+  t.first[count] = blocks;
+  t.n = count;
+  hipLaunchKernelGGL(dw_wgrad_finalize_multi_kernel, dim3(blocks), dim3(1024), 0, (hipStream_t)s, t);
+  return uh_check_launch("dw_wgrad_finalize_multi");
 }
 
 // ---- attention gate, pointwise parts (C >= 64; z = [z1 | z2 | z3] pre-activations, 3C channels) ----------------------

@@ -89,6 +89,7 @@ class LUNeXtRun:
         self._bn_sums = {}
         self._pending = {}
         self._dx_colsum = {}
+        self._dw_wgrads = []
         self.packer = lunext_packer_for(module, x.device)       # bf16 GEMM operands, one repack launch per direction
         self.wf = None
         # set by a caller that keeps all parameter gradients in one flat buffer (dp.FlatGrads, laid out by
@@ -235,8 +236,8 @@ class LUNeXtRun:
                 call("uh_dwblock_bwd", B, H, W, Cp, da.ptr, da.cstride, da.coff, y.ptr, y.cstride, y.coff, x.ptr,
                      x.cstride, x.coff, rec.wt.data_ptr(), C, *st, coef.data_ptr(), dx.ptr, dx.cstride,
                      dx.coff, wp.data_ptr(), s)
-            with self._side() as s2:
-                call("uh_dw_wgrad_finalize", wp.data_ptr(), wparts, Cp, C, dw.data_ptr(), s2)
+            # the partial rows are added up later, many layers per launch (_flush_dw_wgrads)
+            self._dw_wgrads.append(_lib.DwFinDesc(wp.data_ptr(), dw.data_ptr(), wparts, Cp, C))
             grads[name + ".depthwise.weight"] = dw
             grads[name + ".depthwise.bias"] = self._gzero(name + ".depthwise.bias", C)
             return dx
@@ -257,6 +258,16 @@ class LUNeXtRun:
         call("uh_dwconv3x3_dgrad", B, H, W, Cp, dy.ptr, dy.cstride, dy.coff, rec.wt.data_ptr(), C, dr.ptr, dr.cstride,
              dr.coff, mask.data_ptr(), dx.ptr, dx.cstride, dx.coff, s)
         return dx
+
+    def _flush_dw_wgrads(self):
+        """The depthwise weight gradients whose partial rows are waiting: one launch on the second stream (18 separate
+        ones, each behind a stream dependency of its own, cost the step 0.13 ms)."""
+        todo, self._dw_wgrads = self._dw_wgrads, []
+        for lo in range(0, len(todo), _lib.DWFIN_MAX):
+            part = todo[lo:lo + _lib.DWFIN_MAX]
+            table = (_lib.DwFinDesc * len(part))(*part)
+            with self._side() as s2:
+                call("uh_dw_wgrad_finalize_multi", table, len(part), s2)
 
     # ------------------------------------------------------------------ 2x2 stride-2 conv (lunext.py:139-154)
     @ranged(lambda l, *a: f"fwd/downconv{l + 1}")
@@ -629,12 +640,14 @@ class LUNeXtRun:
             skip_grads[l] = dx
             da = self._up_backward(k, dg, grads)
         da = self._dw_backward("conv5_1", self._dw_backward("conv5_2", da, grads, prev="conv5_1"), grads, colsum=True)
+        self._flush_dw_wgrads()                     # the decoder's and the bridge's, beside the encoder's backward
         for l in range(4, 0, -1):
             if (l - 1) in self._skip_ready:
                 self._main.wait_event(self._skip_ready[l - 1])
             tot = self._down_backward(l, da, grads, skip_grads[l - 1])
             da = self._dw_backward(f"conv{l}_1", self._dw_backward(f"conv{l}_2", tot, grads, prev=f"conv{l}_1"), grads,
                                    colsum=l > 1)
+        self._flush_dw_wgrads()
         if self._side_used is not None:
             self._main.wait_stream(self._side_used)
         return grads
