@@ -363,6 +363,13 @@ class LUNeXtRun:
             call("uh_resize_bilinear_bwd", B, 2 * Hs, 2 * Ws, H, W, cpo, dup.ptr, dup.cstride, dup.coff, raw.ptr,
                  raw.cstride, raw.coff, s)
             dup = raw
+        d4 = Ls.act(Bs, Hs, Ws, N, tag=f"up{k}.d4")
+        call("uh_space_to_depth2", Bs, Hs, Ws, cpo, dup.ptr, dup.cstride, dup.coff, d4.ptr, d4.cstride, 0, s)
+        S = L.uh_conv_wgrad_splits(Bs, Hs, Ws, N, cin, 1)
+        part = Ls.f32(S * N * cin)
+        dw = self._gnew(f"upconv{k}.weight", up.weight.shape)  # [cin][cout][2][2]
+        # one visit to the second stream for the bias and the weight gradient (every visit is an event on the main
+        # stream, which costs it a few microseconds)
         with self._side() as s2:
             if self.gflat is None:
                 grads[f"upconv{k}.bias"] = self._colsum(dup, cpo, s2)[:cout]   # a view of a tensor made for this gradient
@@ -371,12 +378,6 @@ class LUNeXtRun:
             else:                                                  # padded channels: only the first cout sums are wanted
                 grads[f"upconv{k}.bias"] = self._colsum(dup, cpo, s2, out=self.gflat.views[f"upconv{k}.bias"],
                                                         cols=self._table(("first", cout), lambda: list(range(cout))))
-        d4 = Ls.act(Bs, Hs, Ws, N, tag=f"up{k}.d4")
-        call("uh_space_to_depth2", Bs, Hs, Ws, cpo, dup.ptr, dup.cstride, dup.coff, d4.ptr, d4.cstride, 0, s)
-        S = L.uh_conv_wgrad_splits(Bs, Hs, Ws, N, cin, 1)
-        part = Ls.f32(S * N * cin)
-        dw = self._gnew(f"upconv{k}.weight", up.weight.shape)  # [cin][cout][2][2]
-        with self._side() as s2:
             call("uh_conv_wgrad", Bs, Hs, Ws, d4.ptr, d4.cstride, 0, N, x.ptr, x.cstride, x.coff, cin, 1, part.data_ptr(), s2)
             call("uh_wgrad_reduce_strided", part.data_ptr(), S, N * cin, cout, 4, cin, cin, cpo * cin, 4, 1, cout * 4,
                  dw.data_ptr(), 0, s2)
@@ -529,6 +530,9 @@ class LUNeXtRun:
         part3 = Ls.f32(S3 * C * C)
         names = ("sigmoid_conv", "tanh_conv", "combine_conv")
         dws = [self._gnew(pre + nm + ".weight", (C, C, 1, 1)) for nm in names]
+        wd3 = self.wb[f"att{k}.wd3"]
+        ds = Ls.act(B, H, W, C)
+        dx = Ls.act(B, H, W, C)
         with self._side() as s2:
             # in a flat gradient buffer the three biases lie side by side (flat_param_order)
             db = (torch.empty(3 * C, dtype=torch.float32, device=self.device) if self.gflat is None else
@@ -542,20 +546,9 @@ class LUNeXtRun:
             call("uh_conv_wgrad", B, H, W, dz.ptr, dz.cstride, 2 * C, C, ssum.ptr, ssum.cstride, ssum.coff, C, 1,
                  part3.data_ptr(), s2)
             call("uh_wgrad_reduce", part3.data_ptr(), S3, C, 1, C, C, 0, C, 0, 1, dws[2].data_ptr(), 0, s2)
-        for j, nm in enumerate(("sigmoid_conv", "tanh_conv", "combine_conv")):
-            grads[pre + nm + ".bias"] = db[j * C:(j + 1) * C]
-            grads[pre + nm + ".weight"] = dws[j]
-        # input gradients: dg = sum_j dz_j W_j (one GEMM over K = 3C),  ds = dz_3 W_3,  dx = dout*a + ds
-        wd = self.wb[f"att{k}.wd"]
-        dg = Ls.act(B, H, W, C)
-        call("uh_conv_gemm", B, H, W, dz.ptr, dz.cstride, 0, 3 * C, wd.data_ptr(), C, 1, EPI_MASKED, dg.ptr,
-             dg.cstride, dg.coff, None, None, None, None, mask.data_ptr(), s)
-        # dx is the gradient of the skip connection: nothing needs it before the encoder's backward reaches this level,
-        # so its two launches go to the second stream too (backward() makes the main stream wait for `ready` there)
-        wd3 = self.wb[f"att{k}.wd3"]
-        ds = Ls.act(B, H, W, C)
-        dx = Ls.act(B, H, W, C)
-        with self._side() as s2:
+            # dx = dout * a + dz_3 W_3 is the gradient of the skip connection: nothing needs it before the encoder's
+            # backward reaches this level, so its two launches are on the second stream too, in the same visit
+            # (backward() makes the main stream wait for `ready` there)
             call("uh_conv_gemm", B, H, W, dz.ptr, dz.cstride, 2 * C, C, wd3.data_ptr(), C, 1, EPI_MASKED, ds.ptr,
                  ds.cstride, ds.coff, None, None, None, None, mask.data_ptr(), s2)
             call("uh_add", g.Mp, C, dxd.ptr, dxd.cstride, dxd.coff, ds.ptr, ds.cstride, ds.coff, None, 0, 0, dx.ptr,
@@ -564,6 +557,14 @@ class LUNeXtRun:
             ready = torch.cuda.Event()
             ready.record(self._side_st)
             self._skip_ready[l] = ready
+        for j, nm in enumerate(("sigmoid_conv", "tanh_conv", "combine_conv")):
+            grads[pre + nm + ".bias"] = db[j * C:(j + 1) * C]
+            grads[pre + nm + ".weight"] = dws[j]
+        # input gradients: dg = sum_j dz_j W_j (one GEMM over K = 3C),  ds = dz_3 W_3,  dx = dout*a + ds
+        wd = self.wb[f"att{k}.wd"]
+        dg = Ls.act(B, H, W, C)
+        call("uh_conv_gemm", B, H, W, dz.ptr, dz.cstride, 0, 3 * C, wd.data_ptr(), C, 1, EPI_MASKED, dg.ptr,
+             dg.cstride, dg.coff, None, None, None, None, mask.data_ptr(), s)
         return dg, dx
 
     # ------------------------------------------------------------------ whole network
