@@ -255,6 +255,24 @@ int uh_colsum_finalize(const float* partial, int P, int C, int fold, float* out,
  * written straight into the layout of the parameter gradients they are (autograd's accumulation of lunext.py's padded
  * 3-channel level and of several biases summed in one pass), no copies behind it */
 int uh_colsum_finalize_gather(const float* partial, int P, int C, int n_out, const int* cols, float* out, uh_stream s);
+/* Up to UH_REDUCE_MAX of these small reductions in ONE launch (a LUNeXt backward pass has some thirty of them, nothing
+ * but the optimizer waits for their results): descs is a HOST array, copied into the launch's arguments.
+ *   UH_REDUCE_COLSUM: out[i] (+)= sum_p partial[p][cols ? cols[i] : i], i < n_out  (uh_colsum_finalize with fold 1,
+ *                     uh_colsum_finalize_gather); rows = P
+ *   UH_REDUCE_WGRAD:  uh_wgrad_reduce_strided's arguments; rows = S.  3x3 weight gradients (T = 9 in OIHW order) are not
+ *                     taken: their reductions have kernels of their own. */
+#define UH_REDUCE_MAX 24
+enum { UH_REDUCE_COLSUM = 0, UH_REDUCE_WGRAD = 1 };
+typedef struct {
+  int kind, rows, accumulate;
+  int C, n_out;                              /* column sums */
+  int N, T, K;                               /* weight gradient */
+  const float* partial;
+  float* out;
+  const int* cols;                           /* device array or NULL */
+  long long split_stride, on, ot, sn, st, sk;
+} uh_reduce_desc;
+int uh_reduce_multi(const uh_reduce_desc* descs, int count, uh_stream s);
 
 /* ---- 1x1 segmentation head Conv2d(C -> OC) (unet.py:173; lunext.py:257), fp32 NCHW logits ------ */
 int uh_head_fwd(int B, int H, int W, int C, int OC, const void* a, int a_cstride, int a_coff,

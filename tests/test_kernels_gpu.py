@@ -1061,6 +1061,66 @@ def test_depthwise_weight_gradient_tables_added_up_in_one_launch():
         call("uh_dw_wgrad_finalize_multi", descs, _lib.DWFIN_MAX + 1, S())
 
 
+def test_small_reductions_in_one_launch():
+    """uh_reduce_multi against the single launches it stands for: weight-gradient reductions of every route (transposed
+    convolution, few and many splits) bit for bit, column sums (plain, gathered, accumulating) to double rounding."""
+    g = torch.Generator().manual_seed(101)
+    R = _lib.ReduceDesc
+    descs, checks, keep = [], [], []
+
+    def wgrad(ns, N, T, K, on, ot, sn, st, sk, total_out, split_stride=None, accumulate=0):
+        split_stride = split_stride or N * T * K
+        part = torch.randn(ns, split_stride, generator=g).to(DEV)
+        base = torch.randn(total_out, generator=g).to(DEV)
+        one, many = base.clone(), base.clone()
+        call("uh_wgrad_reduce_strided", part.data_ptr(), ns, split_stride, N, T, K, on, ot, sn, st, sk, one.data_ptr(),
+             accumulate, S())
+        descs.append(R.wgrad(part.data_ptr(), ns, split_stride, N, T, K, on, ot, sn, st, sk, many.data_ptr(), accumulate))
+        checks.append((one, many, True))
+        keep.append(part)
+
+    cin, cout = 64, 128
+    wgrad(7, cout, 4, cin, cin, cout * cin, 4, 1, 4 * cout, cin * cout * 4)                    # transposed convolution
+    wgrad(96, 64, 1, 64, 64, 0, 64, 0, 1, 64 * 64)                                           # many splits, small tensor
+    wgrad(5, 128, 4, 24, 32, 1, 4, 1, 128 * 4 + 7, 128 * 24 * 4 + 4 * 128 * 8, 128 * 4 * 32)  # few splits, odd strides
+    wgrad(3, 64, 1, 64, 64, 0, 64, 0, 1, 64 * 64, accumulate=1)
+
+    def colsum(P, C, n_out=None, cols=None, accumulate=0):
+        part = torch.randn(P, C, generator=g).to(DEV)
+        n = n_out or C
+        base = torch.randn(n, generator=g).to(DEV)
+        one, many = base.clone(), base.clone()
+        if cols is None:
+            call("uh_colsum_finalize", part.data_ptr(), P, C, 1, one.data_ptr(), accumulate, S())
+            descs.append(R.colsum(part.data_ptr(), P, C, many.data_ptr(), accumulate=accumulate))
+        else:
+            ct = torch.tensor(cols, dtype=torch.int32, device=DEV)
+            call("uh_colsum_finalize_gather", part.data_ptr(), P, C, n, ct.data_ptr(), one.data_ptr(), S())
+            descs.append(R.colsum(part.data_ptr(), P, C, many.data_ptr(), n_out=n, cols=ct.data_ptr()))
+            keep.append(ct)
+        checks.append((one, many, False))
+        keep.append(part)
+
+    colsum(300, 192)
+    colsum(2300, 64, accumulate=1)
+    colsum(17, 216, n_out=5, cols=[3, 215, 0, 64, 64])
+    colsum(1, 8)
+    table = (R * len(descs))(*descs)
+    call("uh_reduce_multi", table, len(descs), S())
+    torch.cuda.synchronize()
+    for one, many, exact in checks:
+        if exact:
+            assert torch.equal(one, many)
+        else:
+            torch.testing.assert_close(many, one, rtol=1e-6, atol=1e-6)
+    with pytest.raises(RuntimeError):
+        call("uh_reduce_multi", table, _lib.REDUCE_MAX + 1, S())
+    # a 3x3 weight gradient is not taken
+    with pytest.raises(RuntimeError):
+        bad = (R * 1)(R.wgrad(keep[0].data_ptr(), 2, 64 * 9 * 64, 64, 9, 64, 9 * 64, 64, 9 * 64, 1, 9, checks[0][1].data_ptr()))
+        call("uh_reduce_multi", bad, 1, S())
+
+
 # ---- AttentionGate kernels (lunext.py:76-122) ---------------------------------------------------------------------
 @pytest.mark.parametrize("B,H,W,C", [(2, 8, 8, 64), (1, 6, 10, 128), (2, 4, 4, 256)])
 def test_gate_pointwise_forward_backward(B, H, W, C):

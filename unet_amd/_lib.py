@@ -28,6 +28,26 @@ class DwFinDesc(ctypes.Structure):
 
 DWFIN_MAX = 32          # UH_DWFIN_MAX
 
+
+class ReduceDesc(ctypes.Structure):
+    """uh_reduce_desc: one table of uh_reduce_multi"""
+    _fields_ = [("kind", I), ("rows", I), ("accumulate", I), ("C", I), ("n_out", I), ("N", I), ("T", I), ("K", I),
+                ("partial", P), ("out", P), ("cols", P),
+                ("split_stride", L), ("on", L), ("ot", L), ("sn", L), ("st", L), ("sk", L)]
+
+    @classmethod
+    def colsum(cls, partial, rows, C, out, n_out=None, cols=None, accumulate=0):
+        return cls(REDUCE_COLSUM, rows, accumulate, C, C if n_out is None else n_out, 0, 0, 0, partial, out, cols,
+                   0, 0, 0, 0, 0, 0)
+
+    @classmethod
+    def wgrad(cls, partial, S, split_stride, N, T, K, on, ot, sn, st, sk, out, accumulate=0):
+        return cls(REDUCE_WGRAD, S, accumulate, 0, 0, N, T, K, partial, out, None, split_stride, on, ot, sn, st, sk)
+
+
+REDUCE_MAX = 24         # UH_REDUCE_MAX
+REDUCE_COLSUM, REDUCE_WGRAD = 0, 1
+
 # name -> (restype, argtypes); mirrors include/unet_hip.h one to one
 SIGNATURES = {
     "uh_last_error": (ctypes.c_char_p, []),
@@ -87,6 +107,7 @@ SIGNATURES = {
     "uh_dwconv3x3_wgrad": (I, [I, I, I, I, P, I, I, P, I, I, P, P]),
     "uh_dw_wgrad_finalize": (I, [P, I, I, I, P, P]),
     "uh_dw_wgrad_finalize_multi": (I, [P, I, P]),
+    "uh_reduce_multi": (I, [P, I, P]),
     "uh_space_to_depth2_of": (I, [I, I, I, I, I, I, P, I, I, P, I, I, P]),
     "uh_depth_to_space2_to": (I, [I, I, I, I, I, I, P, I, I, P, I, I, P]),
     "uh_depth_to_space2_add": (I, [I, I, I, I, I, I, P, I, I, P, I, I, P, I, I, P]),

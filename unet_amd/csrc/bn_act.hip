@@ -5,6 +5,7 @@
 // touches whole rows, and per-channel sums are kept in registers across a grid-stride loop,
 // combined through LDS once per workgroup and written as one partial row per workgroup.
 #include "ew.h"
+#include "reduce_small.h"
 
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ partial, int P, int C, int c_real,
                                                            double count, const float* gamma, const float* beta,
@@ -387,19 +388,7 @@ __global__ __launch_bounds__(256) void colsum_finalize_gather_kernel(const float
                                                                      int n_out, const int* __restrict__ cols,
                                                                      float* __restrict__ out) {
   __shared__ double lds[256];
-  const int i = blockIdx.x * 8 + (threadIdx.x & 7), slot = threadIdx.x >> 3;     // 32 row slots per output
-  double s = 0.0;
-  if (i < n_out) {
-    const int c = cols[i];
-    for (int p = slot; p < P; p += 32) s += (double)partial[(long long)p * C + c];
-  }
-  lds[threadIdx.x] = s;
-  __syncthreads();
-  for (int stride = 16; stride > 0; stride >>= 1) {
-    if (slot < stride) lds[threadIdx.x] += lds[threadIdx.x + stride * 8];
-    __syncthreads();
-  }
-  if (threadIdx.x < 8 && i < n_out) out[i] = (float)lds[threadIdx.x];
+  colsum_gather_body(blockIdx.x, lds, partial, P, C, n_out, cols, out, 0);       // (reduce_small.h)
 }
 
 extern "C" int uh_colsum_finalize_gather(const float* partial, int P, int C, int n_out, const int* cols, float* out,

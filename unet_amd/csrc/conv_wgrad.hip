@@ -13,6 +13,7 @@
 // k slice: 4 (n) x T accumulator tiles.  Partial results of the pixel splits are written to a
 // workspace slab and summed by uh_wgrad_reduce (deterministic, no atomics).
 #include "common.h"
+#include "reduce_small.h"
 #include <cstdlib>
 // The LDS-DMA statements below write M0 and name it as clobbered, so that the compiler's own M0 set-up (it merges
 // identical M0 initialisations when nothing between them modifies the register) never assumes a value across them.
@@ -584,59 +585,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
                                                            int N, int T, int K, long long on, long long ot, long long sn,
                                                            long long st, long long sk, float* __restrict__ grad,
                                                            int accumulate) {
-  constexpr int EPB = 256 / SL;
-  __shared__ float red[SL][EPB];
-  const long long total = (long long)N * T * K;
-  const int e = threadIdx.x % EPB, sl = threadIdx.x / EPB;
-  const long long i = (long long)blockIdx.x * EPB + e;
-  int k = 0, t = 0, n = 0;
-  float v = 0.f;
-  if (i < total) {
-    k = (int)(i % K);
-    const long long r = i / K;
-    t = (int)(r % T);
-    n = (int)(r / T);
-    const float* src = partial + n * on + t * ot + k;
-    for (int sp = sl; sp < S; sp += SL) v += src[sp * split_stride];
-  }
-  red[sl][e] = v;
-  __syncthreads();
-  if (sl == 0 && i < total) {
-    float sum = 0.f;
-#pragma unroll
-    for (int j = 0; j < SL; ++j) sum += red[j][e];
-    const long long dst = n * sn + t * st + k * sk;
-    grad[dst] = accumulate ? grad[dst] + sum : sum;
-  }
+  __shared__ float red[256];
+  wgrad_reduce_body<SL>(blockIdx.x, red, partial, S, split_stride, N, T, K, on, ot, sn, st, sk, grad, accumulate);
 }
 
-// Transposed-conv weights, partial [tap][co][k] -> grad [k][co][tap] (T = 4): one block sums a
-// (64 k) x (4 co) x (4 taps) piece and writes 64-byte runs instead of single floats one row apart.
+// (body in reduce_small.h)
 __global__ __launch_bounds__(256) void wgrad_reduce_convt_kernel(const float* __restrict__ partial, int S,
                                                                  long long split_stride, int Cout, int K,
                                                                  float* __restrict__ grad, int accumulate) {
-  __shared__ float red[4][64][17];
-  const int k0 = blockIdx.x * 64, co0 = blockIdx.y * 4;
-  const int kk = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  float acc[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-  for (int sp = sl; sp < S; sp += 4) {
-    const float* q = partial + sp * split_stride + k0 + kk;
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc[c * 4 + t] += q[((long long)t * Cout + co0 + c) * K];
-  }
-#pragma unroll
-  for (int j = 0; j < 16; ++j) red[sl][kk][j] = acc[j];
-  __syncthreads();
-  for (int o = threadIdx.x; o < 64 * 16; o += 256) {
-    const int r = o >> 4, j = o & 15;
-    const float v = (red[0][r][j] + red[1][r][j]) + (red[2][r][j] + red[3][r][j]);
-    float* dst = grad + ((long long)(k0 + r) * Cout + co0) * 4 + j;
-    *dst = accumulate ? *dst + v : v;
-  }
+  __shared__ float red[UH_WGRAD_REDUCE_CONVT_FLOATS];
+  wgrad_reduce_convt_body(blockIdx.x, blockIdx.y, red, partial, S, split_stride, Cout, K, grad, accumulate);
 }
 
 // The common case, partial [n][9][k] -> OIHW grad[n][k][9]: a direct write would scatter 4-byte stores 36 bytes

@@ -90,6 +90,7 @@ class LUNeXtRun:
         self._pending = {}
         self._dx_colsum = {}
         self._dw_wgrads = []
+        self._reduces = []
         self.packer = lunext_packer_for(module, x.device)       # bf16 GEMM operands, one repack launch per direction
         self.wf = None
         # set by a caller that keeps all parameter gradients in one flat buffer (dp.FlatGrads, laid out by
@@ -236,7 +237,7 @@ class LUNeXtRun:
                 call("uh_dwblock_bwd", B, H, W, Cp, da.ptr, da.cstride, da.coff, y.ptr, y.cstride, y.coff, x.ptr,
                      x.cstride, x.coff, rec.wt.data_ptr(), C, *st, coef.data_ptr(), dx.ptr, dx.cstride,
                      dx.coff, wp.data_ptr(), s)
-            # the partial rows are added up later, many layers per launch (_flush_dw_wgrads)
+            # the partial rows are added up later, many layers per launch (_flush_small)
             self._dw_wgrads.append(_lib.DwFinDesc(wp.data_ptr(), dw.data_ptr(), wparts, Cp, C))
             grads[name + ".depthwise.weight"] = dw
             grads[name + ".depthwise.bias"] = self._gzero(name + ".depthwise.bias", C)
@@ -259,15 +260,26 @@ class LUNeXtRun:
              dr.coff, mask.data_ptr(), dx.ptr, dx.cstride, dx.coff, s)
         return dx
 
-    def _flush_dw_wgrads(self):
-        """The depthwise weight gradients whose partial rows are waiting: one launch on the second stream (18 separate
-        ones, each behind a stream dependency of its own, cost the step 0.13 ms)."""
-        todo, self._dw_wgrads = self._dw_wgrads, []
-        for lo in range(0, len(todo), _lib.DWFIN_MAX):
-            part = todo[lo:lo + _lib.DWFIN_MAX]
-            table = (_lib.DwFinDesc * len(part))(*part)
-            with self._side() as s2:
-                call("uh_dw_wgrad_finalize_multi", table, len(part), s2)
+    def _later(self, desc):
+        """a small reduction (a _lib.ReduceDesc) whose result only the optimizer waits for: run by _flush_small"""
+        self._reduces.append(desc)
+
+    def _flush_small(self):
+        """The small reductions that are waiting -- depthwise weight-gradient tables, weight gradients of the 1x1 / 2x2 /
+        transposed convolutions, column sums -- in one visit to the second stream and two launches (one by one, each
+        behind a launch boundary and most behind a stream dependency of their own, the 18 + 30 of a step cost it
+        0.13 + 0.05 ms)."""
+        dws, self._dw_wgrads = self._dw_wgrads, []
+        reds, self._reduces = self._reduces, []
+        if not dws and not reds:
+            return
+        with self._side() as s2:
+            for lo in range(0, len(dws), _lib.DWFIN_MAX):
+                part = dws[lo:lo + _lib.DWFIN_MAX]
+                call("uh_dw_wgrad_finalize_multi", (_lib.DwFinDesc * len(part))(*part), len(part), s2)
+            for lo in range(0, len(reds), _lib.REDUCE_MAX):
+                part = reds[lo:lo + _lib.REDUCE_MAX]
+                call("uh_reduce_multi", (_lib.ReduceDesc * len(part))(*part), len(part), s2)
 
     # ------------------------------------------------------------------ 2x2 stride-2 conv (lunext.py:139-154)
     @ranged(lambda l, *a: f"fwd/downconv{l + 1}")
@@ -301,14 +313,13 @@ class LUNeXtRun:
             ready = self._dx_colsum.pop(id(dy), None)
             if ready is not None:                     # the launch that wrote dy has left its column sums behind
                 db = self._gnew(f"downconv{l}.bias", (cout,))
-                call("uh_colsum_finalize", ready[0].data_ptr(), ready[1], cout, 1, db.data_ptr(), 0, s2)
+                self._later(_lib.ReduceDesc.colsum(ready[0].data_ptr(), ready[1], cout, db.data_ptr()))
                 grads[f"downconv{l}.bias"] = db
             else:
                 grads[f"downconv{l}.bias"] = self._colsum(dy, cout, s2, out=self._gnew(f"downconv{l}.bias", (cout,)))
             call("uh_conv_wgrad", Bs, Hs, Ws, dy.ptr, dy.cstride, dy.coff, cout, x4.ptr, x4.cstride, 0, K, 1,
                  part.data_ptr(), s2)
-            call("uh_wgrad_reduce_strided", part.data_ptr(), S, cout * K, cout, 4, cin, K, cpi, cin * 4, 1, 4,
-                 dw.data_ptr(), 0, s2)
+            self._later(_lib.ReduceDesc.wgrad(part.data_ptr(), S, cout * K, cout, 4, cin, K, cpi, cin * 4, 1, 4, dw.data_ptr()))
         grads[f"downconv{l}.weight"] = dw
         # dx4[m][t*cpi + ci] = sum_co dy[m][co] * W[co][ci][t]
         wd = self.wb[f"down{l}"]
@@ -379,8 +390,8 @@ class LUNeXtRun:
                 grads[f"upconv{k}.bias"] = self._colsum(dup, cpo, s2, out=self.gflat.views[f"upconv{k}.bias"],
                                                         cols=self._table(("first", cout), lambda: list(range(cout))))
             call("uh_conv_wgrad", Bs, Hs, Ws, d4.ptr, d4.cstride, 0, N, x.ptr, x.cstride, x.coff, cin, 1, part.data_ptr(), s2)
-            call("uh_wgrad_reduce_strided", part.data_ptr(), S, N * cin, cout, 4, cin, cin, cpo * cin, 4, 1, cout * 4,
-                 dw.data_ptr(), 0, s2)
+            self._later(_lib.ReduceDesc.wgrad(part.data_ptr(), S, N * cin, cout, 4, cin, cin, cpo * cin, 4, 1, cout * 4,
+                                              dw.data_ptr()))
         grads[f"upconv{k}.weight"] = dw
         wd = self.wb[f"up{k}"]
         dx = Ls.act(Bs, Hs, Ws, cin)
@@ -427,8 +438,9 @@ class LUNeXtRun:
         return self._zeros(n)
 
     def _colsum(self, a, C, s=None, out=None, cols=None):
-        """column sums of `a` (a bias gradient) on stream s (default: the main stream), into `out` if given; with
-        `cols` (int32 device table) out[i] is the sum of column cols[i]"""
+        """column sums of `a` (a bias gradient) into `out` if given; with `cols` (int32 device table) out[i] is the sum of
+        column cols[i].  The pass over `a` runs on stream s (default: the main stream), its partial rows are added up
+        later with the other small reductions (_flush_small)."""
         s, Ls = (self._sh if s is None else s), self.lease
         parts = L.uh_colsum_parts(a.Mp, C)
         cp = Ls.f32(parts * C)
@@ -436,9 +448,9 @@ class LUNeXtRun:
         if out is None:
             out = torch.empty(C, dtype=torch.float32, device=self.device)
         if cols is not None:
-            call("uh_colsum_finalize_gather", cp.data_ptr(), parts, C, cols.numel(), cols.data_ptr(), out.data_ptr(), s)
+            self._later(_lib.ReduceDesc.colsum(cp.data_ptr(), parts, C, out.data_ptr(), cols.numel(), cols.data_ptr()))
         else:
-            call("uh_colsum_finalize", cp.data_ptr(), parts, C, 1, out.data_ptr(), 0, s)
+            self._later(_lib.ReduceDesc.colsum(cp.data_ptr(), parts, C, out.data_ptr()))
         return out
 
     # ------------------------------------------------------------------ attention gate (lunext.py:76-122)
@@ -502,14 +514,13 @@ class LUNeXtRun:
                                                           for c in range(C)] + [192 + 8 * j + c for j in range(3)
                                                                                 for c in range(C)])
                 out = self.gflat.span(pre + "sigmoid_conv.weight", cols.numel())
-                call("uh_colsum_finalize_gather", part.data_ptr(), parts, 216, cols.numel(), cols.data_ptr(),
-                     out.data_ptr(), s)
+                self._later(_lib.ReduceDesc.colsum(part.data_ptr(), parts, 216, out.data_ptr(), cols.numel(), cols.data_ptr()))
                 for nm in names:
                     grads[pre + nm + ".weight"] = self.gflat.views[pre + nm + ".weight"]
                     grads[pre + nm + ".bias"] = self.gflat.views[pre + nm + ".bias"]
                 return dg, dx
             gw = torch.empty(216, dtype=torch.float32, device=self.device)   # made for these gradients: views below
-            call("uh_colsum_finalize", part.data_ptr(), parts, 216, 1, gw.data_ptr(), 0, s)
+            self._later(_lib.ReduceDesc.colsum(part.data_ptr(), parts, 216, gw.data_ptr()))
             for j, nm in enumerate(names):
                 grads[pre + nm + ".weight"] = gw[64 * j:64 * j + 64].view(8, 8)[:C, :C].reshape(C, C, 1, 1)
                 grads[pre + nm + ".bias"] = gw[192 + 8 * j:192 + 8 * j + C]
@@ -537,15 +548,15 @@ class LUNeXtRun:
             # in a flat gradient buffer the three biases lie side by side (flat_param_order)
             db = (torch.empty(3 * C, dtype=torch.float32, device=self.device) if self.gflat is None else
                   self.gflat.span(pre + "sigmoid_conv.bias", 3 * C))
-            call("uh_colsum_finalize", bpart.data_ptr(), bparts, 3 * C, 1, db.data_ptr(), 0, s2)
+            self._later(_lib.ReduceDesc.colsum(bpart.data_ptr(), bparts, 3 * C, db.data_ptr()))
             call("uh_conv_wgrad", B, H, W, dz.ptr, dz.cstride, 0, 2 * C, g.ptr, g.cstride, g.coff, C, 1,
                  part.data_ptr(), s2)
             for j in range(2):
-                call("uh_wgrad_reduce_strided", part.data_ptr() + j * C * C * 4, S, 2 * C * C, C, 1, C, C, 0, C, 0, 1,
-                     dws[j].data_ptr(), 0, s2)
+                self._later(_lib.ReduceDesc.wgrad(part.data_ptr() + j * C * C * 4, S, 2 * C * C, C, 1, C, C, 0, C, 0, 1,
+                                                  dws[j].data_ptr()))
             call("uh_conv_wgrad", B, H, W, dz.ptr, dz.cstride, 2 * C, C, ssum.ptr, ssum.cstride, ssum.coff, C, 1,
                  part3.data_ptr(), s2)
-            call("uh_wgrad_reduce", part3.data_ptr(), S3, C, 1, C, C, 0, C, 0, 1, dws[2].data_ptr(), 0, s2)
+            self._later(_lib.ReduceDesc.wgrad(part3.data_ptr(), S3, C * C, C, 1, C, C, 0, C, 0, 1, dws[2].data_ptr()))
             # dx = dout * a + dz_3 W_3 is the gradient of the skip connection: nothing needs it before the encoder's
             # backward reaches this level, so its two launches are on the second stream too, in the same visit
             # (backward() makes the main stream wait for `ready` there)
@@ -623,13 +634,12 @@ class LUNeXtRun:
             cols = self._table(("head", oc, cin), lambda: [o * 9 + c for o in range(oc) for c in range(cin)] +
                                [o * 9 + 8 for o in range(oc)])
             out = self.gflat.span("final_conv.weight", cols.numel())       # weight, then bias: side by side
-            call("uh_colsum_finalize_gather", hp.data_ptr(), parts, oc * 9, cols.numel(), cols.data_ptr(),
-                 out.data_ptr(), s)
+            self._later(_lib.ReduceDesc.colsum(hp.data_ptr(), parts, oc * 9, out.data_ptr(), cols.numel(), cols.data_ptr()))
             grads["final_conv.weight"] = self.gflat.views["final_conv.weight"]
             grads["final_conv.bias"] = self.gflat.views["final_conv.bias"]
         else:
             hw = torch.empty(oc, 9, dtype=torch.float32, device=self.device)    # made for these gradients: views below
-            call("uh_colsum_finalize", hp.data_ptr(), parts, oc * 9, 1, hw.data_ptr(), 0, s)
+            self._later(_lib.ReduceDesc.colsum(hp.data_ptr(), parts, oc * 9, hw.data_ptr()))
             grads["final_conv.weight"] = hw[:, :cin].reshape(oc, cin, 1, 1)
             grads["final_conv.bias"] = hw[:, 8]
         skip_grads = [None] * 4
@@ -641,14 +651,14 @@ class LUNeXtRun:
             skip_grads[l] = dx
             da = self._up_backward(k, dg, grads)
         da = self._dw_backward("conv5_1", self._dw_backward("conv5_2", da, grads, prev="conv5_1"), grads, colsum=True)
-        self._flush_dw_wgrads()                     # the decoder's and the bridge's, beside the encoder's backward
+        self._flush_small()                         # the decoder's and the bridge's, beside the encoder's backward
         for l in range(4, 0, -1):
             if (l - 1) in self._skip_ready:
                 self._main.wait_event(self._skip_ready[l - 1])
             tot = self._down_backward(l, da, grads, skip_grads[l - 1])
             da = self._dw_backward(f"conv{l}_1", self._dw_backward(f"conv{l}_2", tot, grads, prev=f"conv{l}_1"), grads,
                                    colsum=l > 1)
-        self._flush_dw_wgrads()
+        self._flush_small()
         if self._side_used is not None:
             self._main.wait_stream(self._side_used)
         return grads
