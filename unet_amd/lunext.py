@@ -19,7 +19,7 @@ import torch.nn as nn
 from . import _lib
 from ._lib import call, EPI_RAW_STATS, EPI_AFFINE_RELU, EPI_MASKED, EPI_CONVT
 from .engine import BN_EPS, BN_MOMENTUM, _stream, side_stream_for, ranged, fused_finalize
-from .layout import pool_for
+from .layout import pool_for, Act
 from .packing import lunext_packer_for
 
 L = _lib.lib
@@ -33,6 +33,9 @@ PAIR_SUMS = os.environ.get("UNET_AMD_LUNEXT_PAIR_SUMS", "1") == "1"
 # UNET_AMD_LUNEXT_PAIR_APPLY=0: the first block of a pair writes its output in a launch of its own
 # (uh_bn_res_relu_apply) instead of leaving it to the second block's convolution (uh_dwconv3x3_fwd_applied).
 PAIR_APPLY = os.environ.get("UNET_AMD_LUNEXT_PAIR_APPLY", "1") == "1"
+# UNET_AMD_LUNEXT_GATE_CONCAT=0: the attention gate adds g + x in a pass of its own and runs two GEMMs, instead of one
+# GEMM over [g | x] held side by side in one buffer (the skip connection and the transposed convolution write there).
+GATE_CONCAT = os.environ.get("UNET_AMD_LUNEXT_GATE_CONCAT", "1") == "1"
 
 
 def _padc(c):
@@ -91,6 +94,7 @@ class LUNeXtRun:
         self._dx_colsum = {}
         self._dw_wgrads = []
         self._reduces = []
+        self._reduces2 = []
         self.packer = lunext_packer_for(module, x.device)       # bf16 GEMM operands, one repack launch per direction
         self.wf = None
         # set by a caller that keeps all parameter gradients in one flat buffer (dp.FlatGrads, laid out by
@@ -113,10 +117,11 @@ class LUNeXtRun:
 
     # ------------------------------------------------------------------ depthwise block
     @ranged(lambda name, *a, **k: "fwd/" + name)
-    def _dw(self, name, x, lvl, defer_apply=False):
+    def _dw(self, name, x, lvl, defer_apply=False, out=None):
         """One DepthwiseConvBlock forward.  defer_apply (training, first block of a pair): the block's output buffer
         is handed on unwritten and noted in self._pending with the record of what is to be applied; the next _dw call
-        then makes it inside its own convolution launch (uh_dwconv3x3_fwd_applied) instead of reading it back."""
+        then makes it inside its own convolution launch (uh_dwconv3x3_fwd_applied) instead of reading it back.
+        out: where the block's output goes (a view of a buffer shared with another tensor), else a buffer of its own."""
         blk = getattr(self.m, name)
         B, H, W = self.geo[lvl]
         C, Cp = blk.depthwise.out_channels, x.C
@@ -125,7 +130,7 @@ class LUNeXtRun:
         if wt.data_ptr() % 16 or not wt.is_contiguous():
             wt = wt.clone(memory_format=torch.contiguous_format)
         mask = self.masks[lvl]
-        a = Ls.act(B, H, W, Cp)
+        a = out if out is not None else Ls.act(B, H, W, Cp)
         if not self.training:
             gamma, beta = _padv(blk.bn.weight, Cp), _padv(blk.bn.bias, Cp)
             rm, rv = _padv(blk.bn.running_mean, Cp), _padv(blk.bn.running_var, Cp, 1.0)
@@ -260,9 +265,10 @@ class LUNeXtRun:
              dr.coff, mask.data_ptr(), dx.ptr, dx.cstride, dx.coff, s)
         return dx
 
-    def _later(self, desc):
-        """a small reduction (a _lib.ReduceDesc) whose result only the optimizer waits for: run by _flush_small"""
-        self._reduces.append(desc)
+    def _later(self, desc, second=False):
+        """a small reduction (a _lib.ReduceDesc) whose result only the optimizer waits for: run by _flush_small.
+        second: in a launch after the others' (it adds to what one of them writes)"""
+        (self._reduces2 if second else self._reduces).append(desc)
 
     def _flush_small(self):
         """The small reductions that are waiting -- depthwise weight-gradient tables, weight gradients of the 1x1 / 2x2 /
@@ -271,15 +277,17 @@ class LUNeXtRun:
         0.13 + 0.05 ms)."""
         dws, self._dw_wgrads = self._dw_wgrads, []
         reds, self._reduces = self._reduces, []
-        if not dws and not reds:
+        reds2, self._reduces2 = self._reduces2, []
+        if not dws and not reds and not reds2:
             return
         with self._side() as s2:
             for lo in range(0, len(dws), _lib.DWFIN_MAX):
                 part = dws[lo:lo + _lib.DWFIN_MAX]
                 call("uh_dw_wgrad_finalize_multi", (_lib.DwFinDesc * len(part))(*part), len(part), s2)
-            for lo in range(0, len(reds), _lib.REDUCE_MAX):
-                part = reds[lo:lo + _lib.REDUCE_MAX]
-                call("uh_reduce_multi", (_lib.ReduceDesc * len(part))(*part), len(part), s2)
+            for group in (reds, reds2):
+                for lo in range(0, len(group), _lib.REDUCE_MAX):
+                    part = group[lo:lo + _lib.REDUCE_MAX]
+                    call("uh_reduce_multi", (_lib.ReduceDesc * len(part))(*part), len(part), s2)
 
     # ------------------------------------------------------------------ 2x2 stride-2 conv (lunext.py:139-154)
     @ranged(lambda l, *a: f"fwd/downconv{l + 1}")
@@ -335,8 +343,8 @@ class LUNeXtRun:
 
     # ------------------------------------------------------------------ transposed conv (lunext.py:161-179)
     @ranged(lambda k, *a: f"fwd/upconv{k}")
-    def _up(self, k, x):
-        """level 5-k -> level 4-k"""
+    def _up(self, k, x, out=None):
+        """level 5-k -> level 4-k; `out`: where the result goes (else a buffer of its own)"""
         l = 4 - k
         up = getattr(self.m, f"upconv{k}")
         cin, cout, cpo = self.chans[l + 1], self.chans[l], self.cp[l]
@@ -345,7 +353,8 @@ class LUNeXtRun:
         s, Ls = self._sh, self.lease
         wp = self.wf[f"up{k}"]
         B, H, W = self.geo[l]
-        out = Ls.act(B, 2 * Hs, 2 * Ws, cpo)
+        dest, exact = out, (2 * Hs, 2 * Ws) == (H, W)
+        out = dest if dest is not None and exact else Ls.act(B, 2 * Hs, 2 * Ws, cpo)
         bias = up.bias.detach()
         if cpo != cout:                                    # 3 real channels carried as 8
             bias = Ls.f32(cpo)
@@ -353,8 +362,8 @@ class LUNeXtRun:
         call("uh_conv_gemm", Bs, Hs, Ws, x.ptr, x.cstride, x.coff, cin, wp.data_ptr(), N, 1, EPI_CONVT, out.ptr,
              out.cstride, out.coff, bias.data_ptr(), None, None, None, self.masks[l + 1].data_ptr(), s)
         self.saved[f"up{k}"] = (x, N)
-        if (2 * Hs, 2 * Ws) != (H, W):                     # lunext.py:226-227 (and :234, :242, :250)
-            fit = Ls.act(B, H, W, cpo)
+        if not exact:                                      # lunext.py:226-227 (and :234, :242, :250)
+            fit = dest if dest is not None else Ls.act(B, H, W, cpo)
             call("uh_resize_bilinear_fwd", B, 2 * Hs, 2 * Ws, H, W, cpo, out.ptr, out.cstride, out.coff, fit.ptr,
                  fit.cstride, fit.coff, s)
             return fit
@@ -471,6 +480,21 @@ class LUNeXtRun:
                  self.masks[l].data_ptr(), out.ptr, out.cstride, out.coff, s)
             self.saved[f"att{k}"] = (g, x, wts)
             return out
+        z = Ls.act(B, H, W, 3 * C)
+        mask = self.masks[l]
+        if g.buf is x.buf and g.cstride == 2 * C and g.coff == 0 and x.coff == C:
+            # [g | x] side by side: one GEMM with the rows [W1 0; W2 0; W3 W3] gives all three pre-activations,
+            # W3 (g + x) included, without g + x (the backward pass makes that sum on its second stream)
+            b1, b2, b3 = (c.bias.detach() for c in (att.sigmoid_conv, att.tanh_conv, att.combine_conv))
+            if b1.data_ptr() + 4 * C == b2.data_ptr() and b2.data_ptr() + 4 * C == b3.data_ptr():
+                b123 = b1                                 # side by side in a flat parameter buffer: read where they are
+            else:
+                b123 = torch.cat([b1, b2, b3])
+            call("uh_conv_gemm", B, H, W, g.ptr, g.cstride, 0, 2 * C, self.wf[f"att{k}.wcat"].data_ptr(), 3 * C, 1,
+                 EPI_MASKED, z.ptr, z.cstride, 0, b123.data_ptr(), None, None, None, mask.data_ptr(), s)
+            call("uh_gate_fwd", g.Mp, C, z.ptr, z.cstride, 0, x.ptr, x.cstride, x.coff, out.ptr, out.cstride, out.coff, s)
+            self.saved[f"att{k}"] = (g, x, None, z)
+            return out
         ssum = Ls.act(B, H, W, C)
         call("uh_add", g.Mp, C, g.ptr, g.cstride, g.coff, x.ptr, x.cstride, x.coff, None, 0, 0, ssum.ptr, ssum.cstride,
              ssum.coff, s)
@@ -480,8 +504,6 @@ class LUNeXtRun:
             b12 = b1                                      # by flat_param_order): read as one 2C vector where they are
         else:
             b12 = torch.cat([b1, b2])
-        z = Ls.act(B, H, W, 3 * C)
-        mask = self.masks[l]
         call("uh_conv_gemm", B, H, W, g.ptr, g.cstride, g.coff, C, w12.data_ptr(), 2 * C, 1, EPI_MASKED, z.ptr,
              z.cstride, 0, b12.data_ptr(), None, None, None, mask.data_ptr(), s)
         call("uh_conv_gemm", B, H, W, ssum.ptr, ssum.cstride, ssum.coff, C, w3.data_ptr(), C, 1, EPI_MASKED, z.ptr,
@@ -535,28 +557,46 @@ class LUNeXtRun:
              x.coff, mask.data_ptr(), dz.ptr, dz.cstride, 0, dxd.ptr, dxd.cstride, dxd.coff, bpart.data_ptr(), s)
         # bias and weight gradients only read dz, g and g + x: on the second stream, beside the input gradients below
         # (weight gradients: [dW1; dW2] = dz[:, :2C]^T g,  dW3 = dz[:, 2C:]^T (g + x))
-        S = L.uh_conv_wgrad_splits(B, H, W, 2 * C, C, 1)
-        part = Ls.f32(S * 2 * C * C)
-        S3 = L.uh_conv_wgrad_splits(B, H, W, C, C, 1)
-        part3 = Ls.f32(S3 * C * C)
+        concat = ssum is None                         # the forward pass ran on [g | x] and never made g + x
         names = ("sigmoid_conv", "tanh_conv", "combine_conv")
         dws = [self._gnew(pre + nm + ".weight", (C, C, 1, 1)) for nm in names]
         wd3 = self.wb[f"att{k}.wd3"]
         ds = Ls.act(B, H, W, C)
         dx = Ls.act(B, H, W, C)
+        if concat:
+            # one weight-gradient GEMM dz^T [g | x] (3C x 2C): its blocks (1, g), (2, g) are dW1, dW2 and
+            # (3, g) + (3, x) is dW3 = dz_3^T (g + x) -- the same bytes as the two GEMMs over g and g + x, one launch
+            # less and no g + x
+            S = L.uh_conv_wgrad_splits(B, H, W, 3 * C, 2 * C, 1)
+            part = Ls.f32(S * 6 * C * C)
+        else:
+            S = L.uh_conv_wgrad_splits(B, H, W, 2 * C, C, 1)
+            part = Ls.f32(S * 2 * C * C)
+            S3 = L.uh_conv_wgrad_splits(B, H, W, C, C, 1)
+            part3 = Ls.f32(S3 * C * C)
         with self._side() as s2:
             # in a flat gradient buffer the three biases lie side by side (flat_param_order)
             db = (torch.empty(3 * C, dtype=torch.float32, device=self.device) if self.gflat is None else
                   self.gflat.span(pre + "sigmoid_conv.bias", 3 * C))
             self._later(_lib.ReduceDesc.colsum(bpart.data_ptr(), bparts, 3 * C, db.data_ptr()))
-            call("uh_conv_wgrad", B, H, W, dz.ptr, dz.cstride, 0, 2 * C, g.ptr, g.cstride, g.coff, C, 1,
-                 part.data_ptr(), s2)
-            for j in range(2):
-                self._later(_lib.ReduceDesc.wgrad(part.data_ptr() + j * C * C * 4, S, 2 * C * C, C, 1, C, C, 0, C, 0, 1,
-                                                  dws[j].data_ptr()))
-            call("uh_conv_wgrad", B, H, W, dz.ptr, dz.cstride, 2 * C, C, ssum.ptr, ssum.cstride, ssum.coff, C, 1,
-                 part3.data_ptr(), s2)
-            self._later(_lib.ReduceDesc.wgrad(part3.data_ptr(), S3, C * C, C, 1, C, C, 0, C, 0, 1, dws[2].data_ptr()))
+            if concat:
+                call("uh_conv_wgrad", B, H, W, dz.ptr, dz.cstride, 0, 3 * C, g.ptr, g.cstride, 0, 2 * C, 1,
+                     part.data_ptr(), s2)
+                for j in range(3):                            # the blocks over g: rows j C .. of 2C columns each
+                    self._later(_lib.ReduceDesc.wgrad(part.data_ptr() + j * C * 2 * C * 4, S, 6 * C * C, C, 1, C, 2 * C,
+                                                      0, C, 0, 1, dws[j].data_ptr()))
+                # ... and the block (3, x) on top of dW3, in a launch after the one that wrote it
+                self._later(_lib.ReduceDesc.wgrad(part.data_ptr() + (2 * C * 2 * C + C) * 4, S, 6 * C * C, C, 1, C, 2 * C,
+                                                  0, C, 0, 1, dws[2].data_ptr(), accumulate=1), second=True)
+            else:
+                call("uh_conv_wgrad", B, H, W, dz.ptr, dz.cstride, 0, 2 * C, g.ptr, g.cstride, g.coff, C, 1,
+                     part.data_ptr(), s2)
+                for j in range(2):
+                    self._later(_lib.ReduceDesc.wgrad(part.data_ptr() + j * C * C * 4, S, 2 * C * C, C, 1, C, C, 0, C, 0, 1,
+                                                      dws[j].data_ptr()))
+                call("uh_conv_wgrad", B, H, W, dz.ptr, dz.cstride, 2 * C, C, ssum.ptr, ssum.cstride, ssum.coff, C, 1,
+                     part3.data_ptr(), s2)
+                self._later(_lib.ReduceDesc.wgrad(part3.data_ptr(), S3, C * C, C, 1, C, C, 0, C, 0, 1, dws[2].data_ptr()))
             # dx = dout * a + dz_3 W_3 is the gradient of the skip connection: nothing needs it before the encoder's
             # backward reaches this level, so its two launches are on the second stream too, in the same visit
             # (backward() makes the main stream wait for `ready` there)
@@ -587,15 +627,23 @@ class LUNeXtRun:
         cin = self.chans[0]
         cur = Ls.act(B, H, W, 8)
         call("uh_nchw_to_c8", B, cin, H, W, self.x.data_ptr(), cur.ptr, cur.cstride, cur.coff, s)
-        skips = []
+        skips, pair = [], {}
         for l in range(1, 5):                                   # lunext.py:199-216
-            cur = self._dw(f"conv{l}_2", self._dw(f"conv{l}_1", cur, l - 1, defer_apply=True), l - 1)
+            lv, Cl = l - 1, self.chans[l - 1]
+            if GATE_CONCAT and Cl >= 64:
+                # the skip connection x of this level and the transposed convolution's output g that meets it in the
+                # attention gate share one buffer, [g | x] per position, which the gate's GEMM reads in one go
+                Bl, Hl, Wl = self.geo[lv]
+                gv = Ls.act(Bl, Hl, Wl, Cl, cstride=2 * Cl)
+                pair[lv] = (gv, Act(gv.buf, Bl, Hl, Wl, Cl, 2 * Cl, Cl, gv.guard))
+            cur = self._dw(f"conv{l}_2", self._dw(f"conv{l}_1", cur, lv, defer_apply=True), lv,
+                           out=pair[lv][1] if lv in pair else None)
             skips.append(cur)
             cur = self._down(l, cur)
         cur = self._dw("conv5_2", self._dw("conv5_1", cur, 4, defer_apply=True), 4)
         for k in range(1, 5):                                   # lunext.py:223-254
             l = 4 - k
-            up = self._up(k, cur)
+            up = self._up(k, cur, out=pair[l][0] if l in pair else None)
             cur = self._gate(k, up, skips[l])
             cur = self._dw(f"conv_up{k}_2", self._dw(f"conv_up{k}_1", cur, l, defer_apply=True), l)
         oc = m.out_channels

@@ -112,6 +112,13 @@ def lunext_pack_plan(module):
         entries.append(("fwd", f"att{k}.w12", C * C, att.tanh_conv.weight, C, 1, C, C, 0, 1, C, 0))
         sizes["fwd"][f"att{k}.w3"] = C * C
         entries.append(("fwd", f"att{k}.w3", 0, att.combine_conv.weight, C, 1, C, C, 0, 1, C, 0))
+        # the three 1x1 convolutions as ONE operand over the input [g | x] (2C channels side by side): rows
+        # [W1 0; W2 0; W3 W3], so that W3 (g + x) needs no g + x (the zero blocks are never written)
+        sizes["fwd"][f"att{k}.wcat"] = 3 * C * 2 * C
+        entries.append(("fwd", f"att{k}.wcat", 0, att.sigmoid_conv.weight, C, 1, C, C, 0, 1, 2 * C, 0))
+        entries.append(("fwd", f"att{k}.wcat", C * 2 * C, att.tanh_conv.weight, C, 1, C, C, 0, 1, 2 * C, 0))
+        entries.append(("fwd", f"att{k}.wcat", 2 * C * 2 * C, att.combine_conv.weight, C, 1, C, C, 0, 1, 2 * C, 0))
+        entries.append(("fwd", f"att{k}.wcat", 2 * C * 2 * C + C, att.combine_conv.weight, C, 1, C, C, 0, 1, 2 * C, 0))
         sizes["bwd"][f"att{k}.wd"] = C * 3 * C                         # transposed, side by side along K
         for j, conv in enumerate((att.sigmoid_conv, att.tanh_conv, att.combine_conv)):
             entries.append(("bwd", f"att{k}.wd", j * C, conv.weight, C, 1, C, 1, 0, C, 3 * C, 0))
