@@ -326,6 +326,14 @@ int uh_dwconv3x3_fwd_applied(int B, int H, int W, int C, const void* yq, int yq_
 int uh_bn_res_relu_apply(long long Mp, int C, const void* y, int y_cstride, int y_coff,
                          const void* x, int x_cstride, int x_coff, const float* scale, const float* shift,
                          const uint8_t* rowmask, void* a, int a_cstride, int a_coff, uh_stream s);
+/* uh_bn_res_relu_apply for a block whose output also feeds the 2x2 stride-2 convolution of the next level
+ * (lunext.py:139-154, 203-214): interior values are stored a second time in the space-to-depth layout that convolution's
+ * GEMM reads, depth[(b, y/2, x/2)][d_coff + t*C + c], t = 2 (y & 1) + (x & 1) -- uh_space_to_depth2_of's result without
+ * its pass.  Pad rows of `depth` are not written: they must be zero and stay zero (a buffer only this kernel and
+ * uh_space_to_depth2_of write).  (B, H, W): the block's own geometry. */
+int uh_bn_res_relu_apply_s2d(int B, int H, int W, int C, const void* y, int y_cstride, int y_coff,
+                             const void* x, int x_cstride, int x_coff, const float* scale, const float* shift,
+                             void* a, int a_cstride, int a_coff, void* depth, int d_cstride, int d_coff, uh_stream s);
 int uh_bn_res_relu_bwd_reduce(long long Mp, int C, const void* da, int da_cstride, int da_coff,
                               const void* y, int y_cstride, int y_coff, const void* x, int x_cstride, int x_coff,
                               const float* mean, const float* invstd, const float* scale, const float* shift,

@@ -1042,6 +1042,29 @@ def test_space_to_depth_of_odd_sizes(B, h, w, bigH, bigW, C):
     pads_are_zero(back)
 
 
+@pytest.mark.parametrize("B,H,W,C", [(2, 16, 16, 64), (1, 9, 13, 8), (3, 6, 20, 128), (1, 2, 2, 512)])
+def test_block_output_stored_in_space_to_depth_layout_too(B, H, W, C):
+    """uh_bn_res_relu_apply_s2d against uh_bn_res_relu_apply followed by uh_space_to_depth2_of, odd sizes included."""
+    g = torch.Generator().manual_seed(89)
+    xq = act_from(bf(torch.randn(B, C, H, W, generator=g)))
+    yq = act_from((torch.randn(B, C, H, W, generator=g) * 1.5).half().float(), half=True)
+    sc, sh = (torch.rand(C, generator=g) + 0.5).to(DEV), (torch.randn(C, generator=g) * 0.3).to(DEV)
+    Hs, Ws, K = H // 2, W // 2, max(64, 4 * C)
+    a0, a1 = new_act(B, H, W, C, DEV), new_act(B, H, W, C, DEV)
+    d0, d1 = new_act(B, Hs, Ws, K, DEV), new_act(B, Hs, Ws, K, DEV)             # zero-initialised
+    a1.padded_rows()[:, :] = 3.0
+    call("uh_bn_res_relu_apply", xq.Mp, C, yq.ptr, yq.cstride, yq.coff, xq.ptr, xq.cstride, xq.coff, sc.data_ptr(),
+         sh.data_ptr(), rowmask(B, H, W).data_ptr(), a0.ptr, a0.cstride, a0.coff, S())
+    call("uh_space_to_depth2_of", B, Hs, Ws, C, H, W, a0.ptr, a0.cstride, a0.coff, d0.ptr, d0.cstride, 0, S())
+    call("uh_bn_res_relu_apply_s2d", B, H, W, C, yq.ptr, yq.cstride, yq.coff, xq.ptr, xq.cstride, xq.coff, sc.data_ptr(),
+         sh.data_ptr(), a1.ptr, a1.cstride, a1.coff, d1.ptr, d1.cstride, 0, S())
+    torch.cuda.synchronize()
+    assert torch.equal(a0.padded_rows(), a1.padded_rows())
+    assert torch.equal(d0.buf, d1.buf)
+    assert d1.to_nchw().abs().sum().item() > 0
+    pads_are_zero(d1)
+
+
 def test_depthwise_weight_gradient_tables_added_up_in_one_launch():
     """uh_dw_wgrad_finalize_multi against one uh_dw_wgrad_finalize per table: the same bits."""
     g = torch.Generator().manual_seed(97)

@@ -101,6 +101,7 @@ SIGNATURES = {
     "uh_dw_parts": (I, [I, I, I, I]),
     "uh_dwconv3x3_fwd": (I, [I, I, I, I, P, I, I, P, I, P, I, P, P, P, P, I, I, P, P]),
     "uh_bn_res_relu_apply": (I, [L, I, P, I, I, P, I, I, P, P, P, P, I, I, P]),
+    "uh_bn_res_relu_apply_s2d": (I, [I, I, I, I, P, I, I, P, I, I, P, P, P, I, I, P, I, I, P]),
     "uh_bn_res_relu_bwd_reduce": (I, [L, I, P, I, I, P, I, I, P, I, I, P, P, P, P, P, P]),
     "uh_bn_res_relu_bwd_apply": (I, [L, I, P, I, I, P, I, I, P, I, I, P, P, P, P, P, P, P, I, I, P, I, I, P]),
     "uh_dwconv3x3_dgrad": (I, [I, I, I, I, P, I, I, P, I, P, I, I, P, P, I, I, P]),

@@ -306,6 +306,62 @@ extern "C" int uh_bn_res_relu_apply(long long Mp, int C, const void* y, int y_cs
   return uh_check_launch("bn_res_relu_apply");
 }
 
+// The same pass for a block whose output also feeds a 2x2 stride-2 convolution (lunext.py:139-154): every interior
+// value is stored a second time where that convolution's GEMM reads it, depth[(b, y/2, x/2)][t*C + c] with
+// t = 2 (y & 1) + (x & 1) -- what uh_space_to_depth2_of would copy there in a pass of its own.  Pad rows of `depth` are
+// not written (they are zero in a buffer nothing else writes); a last odd row / column has no place in it.
+__global__ __launch_bounds__(256) void bn_res_relu_apply_s2d_kernel(
+    long long Mp, int C, int H, int W, const char* __restrict__ y, int y_cs, int y_co, const char* __restrict__ x,
+    int x_cs, int x_co, const float* __restrict__ scale, const float* __restrict__ shift, char* __restrict__ a, int a_cs,
+    int a_co, char* __restrict__ depth, int d_cs, int d_co) {
+  const int cpr = C / 8, rpi = 256 / cpr;
+  const int rr = threadIdx.x / cpr, cc = threadIdx.x % cpr;
+  if (rr >= rpi) return;
+  const unsigned Wp = W + 1, Hp = H + 1, Hs = H / 2, Ws = W / 2;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    sc[j] = scale[cc * 8 + j];
+    sh[j] = shift[cc * 8 + j];
+  }
+  for (long long m = (long long)blockIdx.x * rpi + rr; m < Mp; m += (long long)gridDim.x * rpi) {
+    const unsigned mu = (unsigned)m, px = mu % Wp, r = mu / Wp, py = r % Hp, b = r / Hp;
+    U4 o = {0u, 0u, 0u, 0u};
+    const U4 yr = *(const U4*)(y + (m * y_cs + y_co + cc * 8) * 2);
+    const U4 xr = *(const U4*)(x + (m * x_cs + x_co + cc * 8) * 2);
+    const bool interior = (py < (unsigned)H) & (px < (unsigned)W);
+    if (interior) {
+      float f[8], q[8];
+      unpack8h(yr, f);
+      unpack8(xr, q);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j] * sc[j] + sh[j] + q[j], 0.f);
+      o = pack8(f);
+    }
+    *(U4*)(a + (m * a_cs + a_co + cc * 8) * 2) = o;
+    if (interior & (py < 2 * Hs) & (px < 2 * Ws)) {
+      const long long ms = ((long long)b * (Hs + 1) + (py >> 1)) * (Ws + 1) + (px >> 1);
+      const int t = ((py & 1) << 1) | (px & 1);
+      *(U4*)(depth + (ms * d_cs + d_co + t * C + cc * 8) * 2) = o;
+    }
+  }
+}
+
+extern "C" int uh_bn_res_relu_apply_s2d(int B, int H, int W, int C, const void* y, int y_cstride, int y_coff,
+                                        const void* x, int x_cstride, int x_coff, const float* scale,
+                                        const float* shift, void* a, int a_cstride, int a_coff, void* depth,
+                                        int d_cstride, int d_coff, uh_stream s) {
+  EW_CHECK("bn_res_relu_apply_s2d", C);
+  UH_REQUIRE(B > 0 && H >= 2 && W >= 2 && y && x && scale && shift && a && depth, "bn_res_relu_apply_s2d: bad arguments");
+  UH_REQUIRE(d_cstride % 8 == 0 && d_coff % 8 == 0 && d_cstride >= d_coff + 4 * C, "bn_res_relu_apply_s2d: bad depth view");
+  const long long Mp = uh_mp(B, H, W);
+  UH_REQUIRE(Mp < (1ll << 31), "bn_res_relu_apply_s2d: %lld positions", Mp);
+  hipLaunchKernelGGL(bn_res_relu_apply_s2d_kernel, dim3(ew_blocks(Mp, C)), dim3(256), 0, (hipStream_t)s, Mp, C, H, W,
+                     (const char*)y, y_cstride, y_coff, (const char*)x, x_cstride, x_coff, scale, shift, (char*)a,
+                     a_cstride, a_coff, (char*)depth, d_cstride, d_coff);
+  return uh_check_launch("bn_res_relu_apply_s2d");
+}
+
 // backward: d = da * (y*scale + shift + x > 0); partial = (sum d, sum d*xhat)
 __global__ __launch_bounds__(256) void bn_res_relu_bwd_reduce_kernel(
     long long Mp, int C, const char* __restrict__ da, int da_cs, int da_co, const char* __restrict__ y, int y_cs,

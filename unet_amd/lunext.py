@@ -36,6 +36,9 @@ PAIR_APPLY = os.environ.get("UNET_AMD_LUNEXT_PAIR_APPLY", "1") == "1"
 # UNET_AMD_LUNEXT_GATE_CONCAT=0: the attention gate adds g + x in a pass of its own and runs two GEMMs, instead of one
 # GEMM over [g | x] held side by side in one buffer (the skip connection and the transposed convolution write there).
 GATE_CONCAT = os.environ.get("UNET_AMD_LUNEXT_GATE_CONCAT", "1") == "1"
+# UNET_AMD_LUNEXT_S2D_FUSED=0: the space-to-depth operand of a 2x2 stride-2 convolution is made by a pass of its own
+# (uh_space_to_depth2_of) instead of by the launch that writes the block output it copies (uh_bn_res_relu_apply_s2d).
+S2D_FUSED = os.environ.get("UNET_AMD_LUNEXT_S2D_FUSED", "1") == "1"
 
 
 def _padc(c):
@@ -95,6 +98,8 @@ class LUNeXtRun:
         self._dw_wgrads = []
         self._reduces = []
         self._reduces2 = []
+        self._x4s = {}
+        self._depth_made = set()
         self.packer = lunext_packer_for(module, x.device)       # bf16 GEMM operands, one repack launch per direction
         self.wf = None
         # set by a caller that keeps all parameter gradients in one flat buffer (dp.FlatGrads, laid out by
@@ -117,11 +122,13 @@ class LUNeXtRun:
 
     # ------------------------------------------------------------------ depthwise block
     @ranged(lambda name, *a, **k: "fwd/" + name)
-    def _dw(self, name, x, lvl, defer_apply=False, out=None):
+    def _dw(self, name, x, lvl, defer_apply=False, out=None, depth=None):
         """One DepthwiseConvBlock forward.  defer_apply (training, first block of a pair): the block's output buffer
         is handed on unwritten and noted in self._pending with the record of what is to be applied; the next _dw call
         then makes it inside its own convolution launch (uh_dwconv3x3_fwd_applied) instead of reading it back.
-        out: where the block's output goes (a view of a buffer shared with another tensor), else a buffer of its own."""
+        out: where the block's output goes (a view of a buffer shared with another tensor), else a buffer of its own.
+        depth: the space-to-depth operand of the 2x2 stride-2 convolution that reads this block's output: filled by the
+        same launch that writes the output (training), see _down."""
         blk = getattr(self.m, name)
         B, H, W = self.geo[lvl]
         C, Cp = blk.depthwise.out_channels, x.C
@@ -175,6 +182,11 @@ class LUNeXtRun:
         self.recs[name] = rec
         if defer_apply and PAIR_APPLY and not fused_finalize() and L.uh_dwconv3x3_fwd_takes_apply(Cp):
             self._pending[id(a)] = rec
+            return a
+        if depth is not None and S2D_FUSED:
+            call("uh_bn_res_relu_apply_s2d", B, H, W, Cp, rec.y.ptr, rec.y.cstride, rec.y.coff, x.ptr, x.cstride, x.coff,
+                 rec.scale.data_ptr(), rec.shift.data_ptr(), a.ptr, a.cstride, a.coff, depth.ptr, depth.cstride, 0, s)
+            self._depth_made.add(id(depth))
             return a
         call("uh_bn_res_relu_apply", x.Mp, Cp, rec.y.ptr, rec.y.cstride, rec.y.coff, x.ptr, x.cstride, x.coff,
              rec.scale.data_ptr(), rec.shift.data_ptr(), mask.data_ptr(), a.ptr, a.cstride, a.coff, s)
@@ -290,6 +302,14 @@ class LUNeXtRun:
                     call("uh_reduce_multi", (_lib.ReduceDesc * len(part))(*part), len(part), s2)
 
     # ------------------------------------------------------------------ 2x2 stride-2 conv (lunext.py:139-154)
+    def _x4(self, l, cpi):
+        """the space-to-depth operand of downconv{l} (a private, zero-initialised buffer: its pad rows and the channels
+        beyond 4 * cpi are never written); one per pass"""
+        if l not in self._x4s:
+            Bs, Hs, Ws = self.geo[l]
+            self._x4s[l] = self.lease.act(Bs, Hs, Ws, max(64, 4 * cpi), tag=f"down{l}.x4")
+        return self._x4s[l]
+
     @ranged(lambda l, *a: f"fwd/downconv{l + 1}")
     def _down(self, l, x):
         """level l-1 -> level l"""
@@ -298,8 +318,11 @@ class LUNeXtRun:
         Bs, Hs, Ws = self.geo[l]
         K = max(64, 4 * cpi)
         s, Ls = self._sh, self.lease
-        x4 = Ls.act(Bs, Hs, Ws, K, tag=f"down{l}.x4")
-        call("uh_space_to_depth2_of", Bs, Hs, Ws, cpi, x.H, x.W, x.ptr, x.cstride, x.coff, x4.ptr, x4.cstride, 0, s)
+        x4 = self._x4(l, cpi)
+        if id(x4) in self._depth_made:                   # the launch that wrote x has filled it
+            self._depth_made.discard(id(x4))
+        else:
+            call("uh_space_to_depth2_of", Bs, Hs, Ws, cpi, x.H, x.W, x.ptr, x.cstride, x.coff, x4.ptr, x4.cstride, 0, s)
         wp = self.wf[f"down{l}"]
         out = Ls.act(Bs, Hs, Ws, cout)
         call("uh_conv_gemm", Bs, Hs, Ws, x4.ptr, x4.cstride, 0, K, wp.data_ptr(), cout, 1, EPI_MASKED, out.ptr,
@@ -637,7 +660,8 @@ class LUNeXtRun:
                 gv = Ls.act(Bl, Hl, Wl, Cl, cstride=2 * Cl)
                 pair[lv] = (gv, Act(gv.buf, Bl, Hl, Wl, Cl, 2 * Cl, Cl, gv.guard))
             cur = self._dw(f"conv{l}_2", self._dw(f"conv{l}_1", cur, lv, defer_apply=True), lv,
-                           out=pair[lv][1] if lv in pair else None)
+                           out=pair[lv][1] if lv in pair else None,
+                           depth=self._x4(l, self.cp[lv]) if self.training else None)
             skips.append(cur)
             cur = self._down(l, cur)
         cur = self._dw("conv5_2", self._dw("conv5_1", cur, 4, defer_apply=True), 4)
