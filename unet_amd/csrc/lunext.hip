@@ -1577,9 +1577,40 @@ extern "C" int uh_dwblock_bwd_prev(int B, int H, int W, int C, const void* da, i
 // rows, eight rows fetched before any is added (the strip-walk backward leaves thousands of rows: a chain of one load
 // per row and 32-byte pieces took 20-45 us per launch).  Fixed order, double accumulators.
 __device__ __forceinline__ void dw_wgrad_finalize_block(const float* __restrict__ partial, int P, int C, int c_real,
-                                                        float* __restrict__ out, int blk, double* lds /*[32 * 33]*/) {
-  const int ncol = 9 * C, c0 = blk * 32;
-  const int t = threadIdx.x, cl = t & 31, slot = t >> 5;
+                                                        float* __restrict__ out, int blk, double* lds /*[DWFIN_LDS]*/) {
+  const int ncol = 9 * C;
+  const int t = threadIdx.x;
+  if (ncol <= 128) {
+    // few columns (the 8-channel level, whose tables are the longest): 8 columns and 128 row slots per workgroup, so
+    // that the rows are spread over more threads (34 rows per thread instead of 136 at 4342 rows)
+    const int c0 = blk * 8, c8 = t & 7, slot = t >> 3, col = c0 + c8;
+    double s = 0.0;
+    if (col < ncol) {
+      const float* src = partial + col;
+      int p = slot;
+      for (; p + 7 * 128 < P; p += 8 * 128) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(long long)(p + u * 128) * ncol];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += (double)v[u];
+      }
+      for (; p < P; p += 128) s += (double)src[(long long)p * ncol];
+    }
+    lds[slot * 8 + c8] = s;
+    __syncthreads();
+    for (int stride = 64; stride > 0; stride >>= 1) {
+      if (slot < stride) lds[slot * 8 + c8] += lds[(slot + stride) * 8 + c8];
+      __syncthreads();
+    }
+    if (t < 8 && c0 + t < ncol) {
+      const int tap = (c0 + t) / C, c = (c0 + t) % C;
+      if (c < c_real) out[c * 9 + tap] = (float)lds[t];
+    }
+    return;
+  }
+  const int c0 = blk * 32;
+  const int cl = t & 31, slot = t >> 5;
   const int col = c0 + cl;
   double s = 0.0;
   if (col < ncol) {
@@ -1604,16 +1635,18 @@ __device__ __forceinline__ void dw_wgrad_finalize_block(const float* __restrict_
     if (c < c_real) out[c * 9 + tap] = (float)v;
   }
 }
+#define DWFIN_LDS (32 * 33)
+static inline int dw_wgrad_finalize_blocks(int C) { return 9 * C <= 128 ? (9 * C + 7) / 8 : (9 * C + 31) / 32; }
 
 __global__ __launch_bounds__(1024) void dw_wgrad_finalize_kernel(const float* __restrict__ partial, int P, int C,
                                                                  int c_real, float* __restrict__ out) {
-  __shared__ double lds[32 * 33];
+  __shared__ double lds[DWFIN_LDS];
   dw_wgrad_finalize_block(partial, P, C, c_real, out, blockIdx.x, lds);
 }
 
 extern "C" int uh_dw_wgrad_finalize(const float* partial, int P, int C, int c_real, float* out, uh_stream s) {
   UH_REQUIRE(partial && out && P > 0 && C > 0 && c_real > 0 && c_real <= C, "dw_wgrad_finalize: bad arguments");
-  hipLaunchKernelGGL(dw_wgrad_finalize_kernel, dim3((9 * C + 31) / 32), dim3(1024), 0, (hipStream_t)s, partial, P, C,
+  hipLaunchKernelGGL(dw_wgrad_finalize_kernel, dim3(dw_wgrad_finalize_blocks(C)), dim3(1024), 0, (hipStream_t)s, partial, P, C,
                      c_real, out);
   return uh_check_launch("dw_wgrad_finalize");
 }
@@ -1625,7 +1658,7 @@ struct DwFinTable {
   int n;
 };
 __global__ __launch_bounds__(1024) void dw_wgrad_finalize_multi_kernel(DwFinTable t) {
-  __shared__ double lds[32 * 33];
+  __shared__ double lds[DWFIN_LDS];
   int i = 0;
   while (i + 1 < t.n && (int)blockIdx.x >= t.first[i + 1]) ++i;            // (uniform over the workgroup)
   const uh_dwfin_desc& d = t.d[i];
@@ -1642,7 +1675,7 @@ extern "C" int uh_dw_wgrad_finalize_multi(const uh_dwfin_desc* descs, int count,
                "dw_wgrad_finalize_multi: bad table %d", i);
     t.d[i] = d;
     t.first[i] = blocks;
-    blocks += (9 * d.C + 31) / 32;
+    blocks += dw_wgrad_finalize_blocks(d.C);
   }
   t.first[count] = blocks;
   t.n = count;

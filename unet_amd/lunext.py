@@ -728,6 +728,7 @@ class LUNeXtRun:
             if (l - 1) in self._skip_ready:
                 self._main.wait_event(self._skip_ready[l - 1])
             tot = self._down_backward(l, da, grads, skip_grads[l - 1])
+            self._flush_small()                     # beside this level's blocks; only their own tables are left for the end
             da = self._dw_backward(f"conv{l}_1", self._dw_backward(f"conv{l}_2", tot, grads, prev=f"conv{l}_1"), grads,
                                    colsum=l > 1)
         self._flush_small()
