@@ -45,7 +45,9 @@ int uh_pack_weights(const float* src, void* dst_bf16, int N, int T, int K,
                     long long sn, long long st, long long sk, long long on, long long ot,
                     int reverse, uh_stream s);
 
-/* The same repack for `count` tensors in one launch; the descriptors live in DEVICE memory (all fields 8 bytes). */
+/* The same repack for `count` tensors in one launch; the descriptors live in DEVICE memory (all fields 8 bytes).
+ * reverse: bit 0 = rotated taps as above; bit 1 = the destination holds fp32 instead of bf16 (zero-padded fp32 parameter
+ * tables of the 8-channel kernels, e.g. the [oc][8] head weight, made in the launch that repacks the GEMM operands). */
 typedef struct {
   const float* src;
   void* dst_bf16;
@@ -552,6 +554,14 @@ int uh_soft_skel(int planes, int H, int W, const float* x, float* skel, float* w
 size_t uh_cldice_workspace(int planes, int H, int W);
 int uh_cldice_forward(int planes, int H, int W, const float* y_true, const float* y_pred,
                       float alpha, float smooth, float* workspace, float* loss_out, uh_stream s);
+/* uh_cldice_forward in two halves, for a training loop that has the labels before the prediction
+ * (trainer/training_utils.py:125-148: the batch is there when the model's forward pass starts): uh_cldice_skel_true
+ * leaves skel(y_true) (cl_dice.py:119) in the workspace and touches no other part of it that the second half or the
+ * backward pass read, so it may run on a second stream beside the network; uh_cldice_forward_pred, ordered after it
+ * on the device, does the rest.  Together they give uh_cldice_forward's bits. */
+int uh_cldice_skel_true(int planes, int H, int W, const float* y_true, float* workspace, uh_stream s);
+int uh_cldice_forward_pred(int planes, int H, int W, const float* y_true, const float* y_pred,
+                           float alpha, float smooth, float* workspace, float* loss_out, uh_stream s);
 /* grad_pred = grad_out[0] * dLoss/dy_pred, with autograd's tie rules (first extremum of a pooling window,
  * 1/2:1/2 split in min(), relu'(0)=0, clamp passes the gradient on [0,1]).  Uses the forward's workspace. */
 int uh_cldice_backward(int planes, int H, int W, const float* y_true, const float* y_pred,

@@ -1406,3 +1406,39 @@ def test_depthwise_forward_with_batchnorm_finalised_inside(B, H, W, C, c_real):
     assert torch.isfinite(b["f"]).all()
     if c_real < C:                                                           # padding channels: scale = shift = 0
         assert b["f"][2, c_real:].abs().max().item() == 0 and b["f"][3, c_real:].abs().max().item() == 0
+
+
+def test_repack_launch_writes_the_fp32_tables_of_the_8_channel_level():
+    """descriptors with bit 1 of `reverse` set write fp32: the repack launch of a LUNeXt leaves the tables that
+    uh_gate8_pack and uh_pad_rows_f32 make (gate weights and biases, the head's weight, the last transposed
+    convolution's bias, zero-padded to 8), and both directions of a training step go in one launch"""
+    import unet_amd
+    from unet_amd.packing import lunext_packer_for
+    torch.manual_seed(12)
+    m = unet_amd.LUNeXt(3, 2).to(DEV)
+    pk = lunext_packer_for(m, DEV)
+    wf, wb = pk.get_both(S())
+    att, up, fc = m.att4, m.upconv4, m.final_conv
+    want = torch.full((216,), 7.0, device=DEV)
+    call("uh_gate8_pack", 3, att.sigmoid_conv.weight.data_ptr(), att.sigmoid_conv.bias.data_ptr(),
+         att.tanh_conv.weight.data_ptr(), att.tanh_conv.bias.data_ptr(), att.combine_conv.weight.data_ptr(),
+         att.combine_conv.bias.data_ptr(), want.data_ptr(), S())
+    assert torch.equal(wf["att4.gate8.f32"], want)
+    want = torch.full((8,), 7.0, device=DEV)
+    call("uh_pad_rows_f32", 1, 3, 8, up.bias.data_ptr(), want.data_ptr(), S())
+    assert torch.equal(wf["up4.bias.f32"], want)
+    want = torch.full((2, 8), 7.0, device=DEV)
+    call("uh_pad_rows_f32", 2, 3, 8, fc.weight.data_ptr(), want.data_ptr(), S())
+    assert torch.equal(wf["head.w.f32"].view(2, 8), want)
+    # one launch for both directions == one launch per direction
+    both = {d: {k: v.clone() for k, v in views.items()} for d, views in (("fwd", wf), ("bwd", wb))}
+    pk.mark_dirty()
+    for d in ("fwd", "bwd"):
+        for v in pk.groups[d]["views"].values():
+            v.fill_(3.0)
+    f2, b2 = pk.get("fwd", S()), pk.get("bwd", S())
+    torch.cuda.synchronize()
+    for d, views in (("fwd", f2), ("bwd", b2)):
+        for k, v in views.items():
+            written = both[d][k] != 0                            # zero padding is never written by either
+            assert torch.equal(v[written], both[d][k][written]), (d, k)

@@ -164,3 +164,44 @@ def test_cldice_with_logits_matches_the_autograd_glue():
     assert abs(loss.item() - want.item()) <= 1e-6 * abs(want.item())
     err = (dl - lr.grad).abs().max().item()
     assert err <= 2e-5 * lr.grad.abs().max().item(), (err, lr.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("own_stream", [False, True])
+def test_cldice_labels_prepared_ahead_give_the_same_bits(own_stream):
+    """cldice_prepare (the labels' skeleton, started before the prediction exists, on a second stream or not) followed by
+    cldice_with_logits(prepared=...) == cldice_with_logits alone, twice in a row with different labels (the second call
+    finds the first one's workspace in the allocator)."""
+    from unet_amd.cl_dice import cldice_prepare, cldice_with_logits
+    from unet_amd.engine import side_stream_for
+    g = torch.Generator().manual_seed(16)
+    side = side_stream_for(DEV) if own_stream else None
+    for shape in ((3, 1, 40, 56), (3, 1, 40, 56), (2, 1, 33, 65)):
+        logits = (torch.randn(*shape, generator=g) * 4).to(DEV)
+        mask = (torch.rand(*shape, generator=g) > 0.6).float().to(DEV)
+        prep = cldice_prepare(mask, stream=side)
+        assert (prep.event is not None) == own_stream
+        got = cldice_with_logits(mask, logits, grad_scale=0.5, prepared=prep)
+        want = cldice_with_logits(mask, logits, grad_scale=0.5)
+        torch.cuda.synchronize()
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+        del prep, got, want
+    with pytest.raises(ValueError):
+        cldice_with_logits(mask, logits, prepared=cldice_prepare(mask[:1]))
+
+
+def test_trainer_with_and_without_prepared_labels(monkeypatch):
+    """LUNeXtTrainer's clDice step with the labels' skeleton made beside the forward pass (default) and inside the loss
+    call (UNET_AMD_CLDICE_PREPARE=0): same losses, same parameters, bit for bit."""
+    x, m = batch(2, 3, 32, 48, seed=21)
+    out = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("UNET_AMD_CLDICE_PREPARE", flag)
+        torch.manual_seed(8)
+        model = unet_amd.LUNeXt(3, 1).to(DEV).train()
+        tr = LUNeXtTrainer(model, lr=1e-3, criterion="cl_dice", standalone=True)
+        losses = [tr.train_step(x, m).item() for _ in range(3)]
+        torch.cuda.synchronize()
+        out.append((losses, {k: v.clone() for k, v in model.state_dict().items()}))
+    assert out[0][0] == out[1][0]
+    for k in out[0][1]:
+        assert torch.equal(out[0][1][k], out[1][1][k]), k

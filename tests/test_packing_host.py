@@ -26,11 +26,15 @@ def test_lunext_plan_entries_fit_their_buffers():
     assert keys["fwd"] == set(sizes["fwd"]) and keys["bwd"] == set(sizes["bwd"])
     # four strided convolutions, four transposed convolutions, three gates at 64 channels and more
     assert sum(k.startswith("down") for k in sizes["fwd"]) == 4
-    assert sum(k.startswith("up") for k in sizes["fwd"]) == 4
-    assert sorted(k for k in sizes["fwd"] if k.startswith("att")) == ["att1.w12", "att1.w3", "att2.w12", "att2.w3",
-                                                                      "att3.w12", "att3.w3"]
+    assert sum(k.startswith("up") and not k.endswith(".f32") for k in sizes["fwd"]) == 4
+    assert sorted(k for k in sizes["fwd"] if k.startswith("att") and not k.endswith(".f32")) == \
+        [f"att{k}.{w}" for k in (1, 2, 3) for w in ("w12", "w3", "wcat")]
     # operands narrower than 64 are padded to 64 rows / columns
     assert sizes["fwd"]["down1"] == 64 * 64 and sizes["fwd"]["up4"] == 64 * 64
+    # the fp32 tables of the 8-channel level: the last transposed convolution's bias, its gate's table, the head's weight
+    assert {k: n for k, n in sizes["fwd"].items() if k.endswith(".f32")} == \
+        {"up4.bias.f32": 8, "att4.gate8.f32": 216, "head.w.f32": 8}
+    assert not any(k.endswith(".f32") for k in sizes["bwd"])
 
 
 def test_unet_plan_covers_every_gemm_layer_once_per_direction():

@@ -160,6 +160,8 @@ SIGNATURES = {
     "uh_soft_skel": (I, [I, I, I, P, P, P, P]),
     "uh_cldice_workspace": (Z, [I, I, I]),
     "uh_cldice_forward": (I, [I, I, I, P, P, F, F, P, P, P]),
+    "uh_cldice_skel_true": (I, [I, I, I, P, P, P]),
+    "uh_cldice_forward_pred": (I, [I, I, I, P, P, F, F, P, P, P]),
     "uh_cldice_backward": (I, [I, I, I, P, P, P, P, P, P]),
     "uh_cldice_read_terms": (I, [P, I, I, I, P, P]),
 }

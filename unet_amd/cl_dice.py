@@ -59,24 +59,77 @@ class _ClDiceFn(torch.autograd.Function):
         return None, grad, None, None
 
 
-def cldice_with_logits(y_true, logits, alpha=0.5, smooth=1.0, lo=1e-6, hi=1 - 1e-6, grad_scale=1.0):
+_SEEDS = {}
+
+
+def _seed(value, dev):
+    """A 0-dim device tensor holding `value`, made once per (device, value): the loss's backward reads its upstream
+    gradient from device memory, and a fill launch per step for a constant is a launch too many."""
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device(), value)
+    t = _SEEDS.get(key)
+    if t is None:
+        if len(_SEEDS) > 64:
+            _SEEDS.clear()
+        t = _SEEDS[key] = torch.full((), value, dtype=torch.float32, device=dev)
+    return t
+
+
+class PreparedLabels:
+    """What cldice_prepare hands to cldice_with_logits: the labels as fp32 planes, the loss's workspace with skel(y_true)
+    on its way into it, and the event that says when it is there (None: made on the caller's stream)."""
+    __slots__ = ("yt", "shape", "ws", "event")
+
+
+def cldice_prepare(y_true, stream=None):
+    """The half of cldice_with_logits that needs no prediction: skel(y_true) (cl_dice.py:119).  A training loop has the
+    labels when the network's forward pass starts (training_utils.py:125-148); started then on `stream` (a
+    torch.cuda.Stream other than the current one) the skeleton is made beside the network instead of between its forward
+    and backward passes.  Pass the result as cldice_with_logits(..., prepared=...)."""
+    planes, H, W = _planes(y_true, "y_true")
+    p = PreparedLabels()
+    p.yt, p.shape = y_true.detach().float().contiguous(), tuple(y_true.shape)
+    dev = p.yt.device
+    p.ws = torch.empty(lib.uh_cldice_workspace(planes, H, W) // 4, dtype=torch.float32, device=dev)
+    cur = torch.cuda.current_stream(dev)
+    if stream is None or stream == cur:
+        p.event = None
+        call("uh_cldice_skel_true", planes, H, W, p.yt.data_ptr(), p.ws.data_ptr(), cur.cuda_stream)
+    else:
+        stream.wait_stream(cur)              # the labels are written, the workspace's last user is done
+        call("uh_cldice_skel_true", planes, H, W, p.yt.data_ptr(), p.ws.data_ptr(), stream.cuda_stream)
+        p.event = torch.cuda.Event()
+        p.event.record(stream)
+    return p
+
+
+def cldice_with_logits(y_true, logits, alpha=0.5, smooth=1.0, lo=1e-6, hi=1 - 1e-6, grad_scale=1.0, prepared=None):
     """The trainer's clDice branch (training_utils.py:146-148) without autograd:
         probs = sigmoid(logits).clamp(lo, hi); loss = soft_dice_cldice(alpha, smooth)(y_true, probs)
     returns (loss, grad_scale * d loss / d logits), both from the HIP kernels: one launch for sigmoid + clamp and one for
-    their backward instead of six element-wise launches around the loss."""
+    their backward instead of six element-wise launches around the loss.  prepared: cldice_prepare(y_true)'s result
+    (same bits either way)."""
     planes, H, W = _planes(logits, "logits")
     if y_true.shape != logits.shape:
         raise ValueError(f"y_true {tuple(y_true.shape)} and logits {tuple(logits.shape)} differ")
-    yt = y_true.detach().float().contiguous()
     x = logits.detach().float().contiguous()
     dev, s, n = x.device, _stream(), x.numel()
     probs = torch.empty_like(x)
     call("uh_sigmoid_clamp", n, x.data_ptr(), float(lo), float(hi), probs.data_ptr(), s)
-    ws = torch.empty(lib.uh_cldice_workspace(planes, H, W) // 4, dtype=torch.float32, device=dev)
     loss = torch.empty((), dtype=torch.float32, device=dev)
-    call("uh_cldice_forward", planes, H, W, yt.data_ptr(), probs.data_ptr(), float(alpha), float(smooth),
-         ws.data_ptr(), loss.data_ptr(), s)
-    seed = torch.full((), float(grad_scale), dtype=torch.float32, device=dev)
+    if prepared is None:
+        yt = y_true.detach().float().contiguous()
+        ws = torch.empty(lib.uh_cldice_workspace(planes, H, W) // 4, dtype=torch.float32, device=dev)
+        call("uh_cldice_forward", planes, H, W, yt.data_ptr(), probs.data_ptr(), float(alpha), float(smooth),
+             ws.data_ptr(), loss.data_ptr(), s)
+    else:
+        if prepared.shape != tuple(y_true.shape) or prepared.yt.device != dev:
+            raise ValueError(f"prepared labels {prepared.shape} on {prepared.yt.device} do not belong to this call")
+        yt, ws = prepared.yt, prepared.ws
+        if prepared.event is not None:
+            torch.cuda.current_stream(dev).wait_event(prepared.event)
+        call("uh_cldice_forward_pred", planes, H, W, yt.data_ptr(), probs.data_ptr(), float(alpha), float(smooth),
+             ws.data_ptr(), loss.data_ptr(), s)
+    seed = _seed(float(grad_scale), dev)
     dprobs = torch.empty_like(x)
     call("uh_cldice_backward", planes, H, W, yt.data_ptr(), probs.data_ptr(), ws.data_ptr(), seed.data_ptr(),
          dprobs.data_ptr(), s)

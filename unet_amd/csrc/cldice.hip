@@ -188,7 +188,8 @@ __global__ __launch_bounds__(256) void cldice_sums_kernel(long long n, const flo
 // coef: [0] loss, [1..3] direct gradient dL/dp = c1*t + c2 + c3*skel_t, [4..5] g_skel_pred = c4*t + c5,
 //       [6] dice, [7] cl_dice, [8] tprec, [9] tsens, [10..16] the seven sums
 __global__ __launch_bounds__(256) void cldice_finalize_kernel(const float* __restrict__ partial, int P, float alpha,
-                                                              float smooth, float* __restrict__ coef) {
+                                                              float smooth, float* __restrict__ coef,
+                                                              float* __restrict__ loss_out) {
   __shared__ double red[256][7];
   double s[7] = {0, 0, 0, 0, 0, 0, 0};
   for (int p = threadIdx.x; p < P; p += 256)
@@ -212,7 +213,9 @@ __global__ __launch_bounds__(256) void cldice_finalize_kernel(const float* __res
     const double cl = 1.0 - 2.0 * tprec * tsens / (tprec + tsens);
     const double dcl_dprec = -2.0 * tsens * tsens / ((tprec + tsens) * (tprec + tsens));
     const double dcl_dsens = -2.0 * tprec * tprec / ((tprec + tsens) * (tprec + tsens));
-    coef[0] = (float)((1.0 - alpha) * dice + alpha * cl);
+    const float loss = (float)((1.0 - alpha) * dice + alpha * cl);
+    coef[0] = loss;
+    *loss_out = loss;
     coef[1] = (float)(-(1.0 - alpha) * 2.0 / den);
     coef[2] = (float)((1.0 - alpha) * num / (den * den));
     coef[3] = (float)(alpha * dcl_dsens / (Sst + smooth));
@@ -864,9 +867,10 @@ extern "C" size_t uh_cldice_workspace(int planes, int H, int W) {
   return cldice_ws_floats((long long)planes * H * W) * sizeof(float);
 }
 
-extern "C" int uh_cldice_forward(int planes, int H, int W, const float* y_true, const float* y_pred, float alpha,
-                                 float smooth, float* workspace, float* loss_out, uh_stream s) {
-  UH_REQUIRE(planes > 0 && H > 0 && W > 0 && y_true && y_pred && workspace && loss_out, "cldice_forward: bad arguments");
+// with_true: the soft skeleton of y_true is made here; otherwise uh_cldice_skel_true has left it in the workspace
+static int cldice_forward_impl(const char* what, int planes, int H, int W, const float* y_true, const float* y_pred,
+                               float alpha, float smooth, float* workspace, float* loss_out, bool with_true, uh_stream s) {
+  UH_REQUIRE(planes > 0 && H > 0 && W > 0 && y_true && y_pred && workspace && loss_out, "%s: bad arguments", what);
   hipStream_t st = (hipStream_t)s;
   const long long n = (long long)planes * H * W;
   float* E = workspace;
@@ -877,18 +881,37 @@ extern "C" int uh_cldice_forward(int planes, int H, int W, const float* y_true, 
   float* coef = partial + 7 * SUM_BLOCKS;
   int rc = skel_forward(planes, H, W, y_pred, E, SK, 1, st);
   if (rc) return rc;
-  rc = skel_forward(planes, H, W, y_true, scratch, SKT, 0, st);
-  if (rc) return rc;
+  if (with_true) {
+    rc = skel_forward(planes, H, W, y_true, scratch, SKT, 0, st);
+    if (rc) return rc;
+  }
   int blocks = grid_for(n);
   if (blocks > SUM_BLOCKS) blocks = SUM_BLOCKS;
   hipLaunchKernelGGL(cldice_sums_kernel, dim3(blocks), dim3(256), 0, st, n, y_true, y_pred, SK + 10 * n, SKT, partial);
-  hipLaunchKernelGGL(cldice_finalize_kernel, dim3(1), dim3(256), 0, st, partial, blocks, alpha, smooth, coef);
-  hipError_t e = hipMemcpyAsync(loss_out, coef, sizeof(float), hipMemcpyDeviceToDevice, st);
-  if (e != hipSuccess) {
-    uh_set_error("cldice_forward: copy of the loss failed: %s", hipGetErrorString(e));
-    return UH_ERR_HIP;
-  }
-  return uh_check_launch("cldice_forward");
+  hipLaunchKernelGGL(cldice_finalize_kernel, dim3(1), dim3(256), 0, st, partial, blocks, alpha, smooth, coef, loss_out);
+  return uh_check_launch(what);
+}
+
+extern "C" int uh_cldice_forward(int planes, int H, int W, const float* y_true, const float* y_pred, float alpha,
+                                 float smooth, float* workspace, float* loss_out, uh_stream s) {
+  return cldice_forward_impl("cldice_forward", planes, H, W, y_true, y_pred, alpha, smooth, workspace, loss_out, true, s);
+}
+
+// The half of uh_cldice_forward that needs no prediction: the soft skeleton of y_true, left in the workspace (it touches
+// only the part of the workspace that the prediction's skeleton does not, so it may run on another stream beside
+// whatever produces y_pred); uh_cldice_forward_pred, ordered after it, then does the rest.  Together: the same bits as
+// uh_cldice_forward.
+extern "C" int uh_cldice_skel_true(int planes, int H, int W, const float* y_true, float* workspace, uh_stream s) {
+  UH_REQUIRE(planes > 0 && H > 0 && W > 0 && y_true && workspace, "cldice_skel_true: bad arguments");
+  const long long n = (long long)planes * H * W;
+  float* SKT = workspace + 22 * n;
+  return skel_forward(planes, H, W, y_true, SKT + n, SKT, 0, (hipStream_t)s);
+}
+
+extern "C" int uh_cldice_forward_pred(int planes, int H, int W, const float* y_true, const float* y_pred, float alpha,
+                                      float smooth, float* workspace, float* loss_out, uh_stream s) {
+  return cldice_forward_impl("cldice_forward_pred", planes, H, W, y_true, y_pred, alpha, smooth, workspace, loss_out,
+                             false, s);
 }
 
 extern "C" int uh_cldice_backward(int planes, int H, int W, const float* y_true, const float* y_pred,

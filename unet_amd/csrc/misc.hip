@@ -88,13 +88,15 @@ extern "C" int uh_pack_weights(const float* src, void* dst, int N, int T, int K,
 // The repack is a transpose: in the source the taps of one (n, k) pair are contiguous, in the destination k is.
 // Tensors with N and K multiples of 32 go through 32 x 32 x T tiles in LDS, read in source order (runs of 32*T
 // floats) and written in destination order (runs of 32 bf16); anything else takes the element-wise loop.
+// reverse & 2: the destination holds fp32 (small zero-padded parameter tables of vector kernels, made in the same launch).
 __global__ __launch_bounds__(256) void pack_multi_kernel(const uh_pack_desc* __restrict__ descs) {
   __shared__ float tile[32 * 9 * 33];
   const uh_pack_desc d = descs[blockIdx.y];
   const int N = (int)d.N, T = (int)d.T, K = (int)d.K;
   const float* __restrict__ src = d.src;
   bf16* __restrict__ dst = (bf16*)d.dst_bf16;
-  if (d.st == 1 && T <= 9 && N % 32 == 0 && K % 32 == 0) {
+  const bool rev = (d.reverse & 1) != 0, as_f32 = (d.reverse & 2) != 0;
+  if (d.st == 1 && T <= 9 && N % 32 == 0 && K % 32 == 0 && !as_f32) {
     const int tk = K / 32, ntiles = (N / 32) * tk;
     const bool k_fast = d.sk < d.sn;               // which of n, k is the faster-varying source dimension
     const int per = 32 * T * 32;
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const uh_pack_desc* __r
         const int r = i / T;
         const int a = r & 31, bq = r >> 5;         // a: faster source dimension
         const int nn = k_fast ? bq : a, kk = k_fast ? a : bq;
-        const int t = d.reverse ? (T - 1 - ts) : ts;
+        const int t = rev ? (T - 1 - ts) : ts;
         tile[(nn * T + t) * 33 + kk] = src[(n0 + nn) * d.sn + ts + (k0 + kk) * d.sk];
       }
       __syncthreads();
@@ -125,8 +127,10 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const uh_pack_desc* __r
     const long long r = i / K;
     const int t = (int)(r % T);
     const int n = (int)(r / T);
-    const int ts = d.reverse ? (T - 1 - t) : t;
-    dst[n * d.on + t * d.ot + k] = f2bf(src[n * d.sn + ts * d.st + k * d.sk]);
+    const int ts = rev ? (T - 1 - t) : t;
+    const float v = src[n * d.sn + ts * d.st + k * d.sk];
+    if (as_f32) ((float*)d.dst_bf16)[n * d.on + t * d.ot + k] = v;
+    else dst[n * d.on + t * d.ot + k] = f2bf(v);
   }
 }
 

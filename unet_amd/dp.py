@@ -483,12 +483,12 @@ class LUNeXtTrainer:
         self.grads = FlatGrads(model, flat_param_order(model), aligned=lambda n: n.endswith("depthwise.weight"))
         self.optimizer = FlatAdam(model, self.grads, lr=lr)
 
-    def _loss(self, logits, masks):
+    def _loss(self, logits, masks, prepared=None):
         scale = 1.0 / self.world
         c = self.criterion
         if c == "cl_dice":
             from .cl_dice import cldice_with_logits
-            return cldice_with_logits(masks, logits, grad_scale=scale)
+            return cldice_with_logits(masks, logits, grad_scale=scale, prepared=prepared)
         if c == "bce" and masks.shape == logits.shape:
             return bce_with_logits(logits, masks, scale)
         fn = nn.BCEWithLogitsLoss() if c == "bce" else c
@@ -502,9 +502,15 @@ class LUNeXtTrainer:
         from .lunext import LUNeXtRun
         model = self.model
         model.train()
+        prepared = None
+        if self.criterion == "cl_dice" and os.environ.get("UNET_AMD_CLDICE_PREPARE", "1") != "0":
+            # the labels' soft skeleton needs no prediction: on the second stream, beside the forward pass
+            from .cl_dice import cldice_prepare
+            two = os.environ.get("UNET_AMD_WGRAD_STREAM", "1") != "0"
+            prepared = cldice_prepare(masks, stream=side_stream_for(masks.device) if two else None)
         run = LUNeXtRun(model, images.float().contiguous(), training=True)
         logits = run.forward()
-        loss, dlogits = self._loss(logits, masks)
+        loss, dlogits = self._loss(logits, masks, prepared)
         run.backward(dlogits, gflat=self.grads)
         run.release()
         if self.world > 1:

@@ -379,9 +379,8 @@ class LUNeXtRun:
         dest, exact = out, (2 * Hs, 2 * Ws) == (H, W)
         out = dest if dest is not None and exact else Ls.act(B, 2 * Hs, 2 * Ws, cpo)
         bias = up.bias.detach()
-        if cpo != cout:                                    # 3 real channels carried as 8
-            bias = Ls.f32(cpo)
-            call("uh_pad_rows_f32", 1, cout, cpo, up.bias.data_ptr(), bias.data_ptr(), s)
+        if cpo != cout:                                    # 3 real channels carried as 8: padded by the weight repack
+            bias = self.wf[f"up{k}.bias.f32"]
         call("uh_conv_gemm", Bs, Hs, Ws, x.ptr, x.cstride, x.coff, cin, wp.data_ptr(), N, 1, EPI_CONVT, out.ptr,
              out.cstride, out.coff, bias.data_ptr(), None, None, None, self.masks[l + 1].data_ptr(), s)
         self.saved[f"up{k}"] = (x, N)
@@ -495,10 +494,7 @@ class LUNeXtRun:
         s, Ls = self._sh, self.lease
         out = Ls.act(B, H, W, Cp)
         if Cp == 8:
-            wts = Ls.f32(216)
-            a1, a2, a3 = att.sigmoid_conv, att.tanh_conv, att.combine_conv
-            call("uh_gate8_pack", C, a1.weight.data_ptr(), a1.bias.data_ptr(), a2.weight.data_ptr(), a2.bias.data_ptr(),
-                 a3.weight.data_ptr(), a3.bias.data_ptr(), wts.data_ptr(), s)
+            wts = self.wf[f"att{k}.gate8.f32"]               # the table uh_gate8_pack makes, written by the weight repack
             call("uh_gate8_fwd", g.Mp, C, g.ptr, g.cstride, g.coff, x.ptr, x.cstride, x.coff, wts.data_ptr(),
                  self.masks[l].data_ptr(), out.ptr, out.cstride, out.coff, s)
             self.saved[f"att{k}"] = (g, x, wts)
@@ -645,7 +641,10 @@ class LUNeXtRun:
     def forward(self):
         self._bind_streams()
         m, Ls, s = self.m, self.lease, self._sh
-        self.wf = self.packer.get("fwd", s)
+        if self.training:
+            self.wf, self.wb = self.packer.get_both(s)          # a training step repacks both directions at once
+        else:
+            self.wf = self.packer.get("fwd", s)
         B, H, W = self.geo[0]
         cin = self.chans[0]
         cur = Ls.act(B, H, W, 8)
@@ -672,8 +671,7 @@ class LUNeXtRun:
             cur = self._dw(f"conv_up{k}_2", self._dw(f"conv_up{k}_1", cur, l, defer_apply=True), l)
         oc = m.out_channels
         fc = m.final_conv
-        w = Ls.f32(oc * 8).view(oc, 8)
-        call("uh_pad_rows_f32", oc, cin, 8, fc.weight.data_ptr(), w.data_ptr(), s)
+        w = self.wf["head.w.f32"].view(oc, 8)                    # [oc][cin] zero-padded to 8 by the weight repack
         logits = torch.empty(B, oc, H, W, dtype=torch.float32, device=self.device)
         call("uh_head_fwd", B, H, W, 8, oc, cur.ptr, cur.cstride, cur.coff, w.data_ptr(), fc.bias.data_ptr(),
              logits.data_ptr(), s)

@@ -74,6 +74,17 @@ class WeightPacker:
             g["versions"] = versions
         return g["views"]
 
+    def get_both(self, stream):
+        """(forward operands, input-gradient operands): both directions in ONE launch where both are stale and their
+        descriptor tables lie one behind the other (a training step, whose optimizer changed every weight)."""
+        f, b = self.groups["fwd"], self.groups["bwd"]
+        vf, vb = [p._version for p in f["params"]], [p._version for p in b["params"]]
+        joined = f["desc"].data_ptr() + f["desc"].numel() * 8 == b["desc"].data_ptr()
+        if joined and vf != f["versions"] and vb != b["versions"]:
+            _lib.call("uh_pack_weights_multi", f["desc"].data_ptr(), len(vf) + len(vb), 256, stream)
+            f["versions"], b["versions"] = vf, vb
+        return self.get("fwd", stream), self.get("bwd", stream)
+
 
 def lunext_pack_plan(module):
     """Buffers and entries of every packed operand of a LUNeXt (models/lunext.py:139-185): the 2x2 stride-2
@@ -81,7 +92,8 @@ def lunext_pack_plan(module):
 
     Returns ({direction: {key: elements}}, [(direction, key, element offset, parameter, N, T, K, sn, st, sk, on, ot)]).
     Operands narrower than the 64 columns/rows the GEMM kernels work on are zero-padded: the buffers start as zeros
-    and the repack writes the real entries only."""
+    and the repack writes the real entries only.  Keys ending in ".f32" are fp32 tables (the zero-padded parameters of
+    the 8-channel vector kernels), written by the same launch."""
     chans = [module.in_channels, 64, 128, 256, 512]
     cp = [max(8, (c + 7) // 8 * 8) for c in chans]
     sizes = {"fwd": {}, "bwd": {}}
@@ -104,9 +116,19 @@ def lunext_pack_plan(module):
         sizes["bwd"][f"up{k}"] = cin * N
         entries.append(("bwd", f"up{k}", 0, w, cin, 4, cout, cout * 4, 1, 4, N, cpo))
         C = chans[l]
-        if C < 64:
-            continue                                                  # the 8-channel gate is one fused vector kernel
         att = getattr(module, f"att{k}")
+        if cpo != cout:                                               # few real channels carried as 8
+            sizes["fwd"][f"up{k}.bias.f32"] = cpo
+            entries.append(("fwd", f"up{k}.bias.f32", 0, getattr(module, f"upconv{k}").bias, 1, 1, cout, 0, 0, 1, cpo, 0))
+        if C < 64:
+            if cpo != 8:
+                continue
+            # the 8-channel gate is one fused vector kernel; its table: three [8][8] weights, then three [8] biases
+            sizes["fwd"][f"att{k}.gate8.f32"] = 216
+            for j, conv in enumerate((att.sigmoid_conv, att.tanh_conv, att.combine_conv)):
+                entries.append(("fwd", f"att{k}.gate8.f32", 64 * j, conv.weight, C, 1, C, C, 0, 1, 8, 0))
+                entries.append(("fwd", f"att{k}.gate8.f32", 192 + 8 * j, conv.bias, 1, 1, C, 0, 0, 1, 8, 0))
+            continue
         sizes["fwd"][f"att{k}.w12"] = 2 * C * C                        # [sigmoid_conv; tanh_conv] rows
         entries.append(("fwd", f"att{k}.w12", 0, att.sigmoid_conv.weight, C, 1, C, C, 0, 1, C, 0))
         entries.append(("fwd", f"att{k}.w12", C * C, att.tanh_conv.weight, C, 1, C, C, 0, 1, C, 0))
@@ -124,6 +146,10 @@ def lunext_pack_plan(module):
             entries.append(("bwd", f"att{k}.wd", j * C, conv.weight, C, 1, C, 1, 0, C, 3 * C, 0))
         sizes["bwd"][f"att{k}.wd3"] = C * C
         entries.append(("bwd", f"att{k}.wd3", 0, att.combine_conv.weight, C, 1, C, 1, 0, C, C, 0))
+    fc = module.final_conv                                            # the head's [oc][cin] weight as [oc][8]
+    oc = fc.out_channels
+    sizes["fwd"]["head.w.f32"] = oc * 8
+    entries.append(("fwd", "head.w.f32", 0, fc.weight, oc, 1, chans[0], chans[0], 0, 1, 8, 0))
     return sizes, entries
 
 
@@ -134,19 +160,32 @@ class PlanPacker(WeightPacker):
         self.device = device
         self.groups = {}
         sizes, entries = plan
+        tables = {}
         for direction in ("fwd", "bwd"):
-            start, off = {}, 0
-            for key, n in sizes[direction].items():
-                start[key] = off
-                off += (n + 7) // 8 * 8                                # 16-byte aligned operands
-            flat = torch.zeros(off, dtype=torch.bfloat16, device=device)
-            views = {key: flat[start[key]:start[key] + n] for key, n in sizes[direction].items()}
+            views, where = {}, {}
+            for f32 in (False, True):
+                start, off = {}, 0
+                for key, n in sizes[direction].items():
+                    if key.endswith(".f32") == f32:
+                        start[key] = off
+                        off += (n + 7) // 8 * 8                        # 16-byte aligned operands
+                flat = torch.zeros(off, dtype=torch.float32 if f32 else torch.bfloat16, device=device)
+                for key, o in start.items():
+                    views[key] = flat[o:o + sizes[direction][key]]
+                    where[key] = flat.data_ptr() + o * flat.element_size()
+                if not f32:
+                    main = flat
             mine = [e for e in entries if e[0] == direction]
-            rows = [[p.data_ptr(), flat.data_ptr() + 2 * (start[key] + eoff), N, T, K, 0, sn, st, sk, on, ot]
+            rows = [[p.data_ptr(), where[key] + eoff * views[key].element_size(), N, T, K,
+                     2 if key.endswith(".f32") else 0, sn, st, sk, on, ot]
                     for (_, key, eoff, p, N, T, K, sn, st, sk, on, ot) in mine]
-            desc = torch.tensor(rows, dtype=torch.int64).to(device)
-            self.groups[direction] = dict(flat=flat, views=views, desc=desc, params=[e[3] for e in mine],
+            tables[direction] = rows
+            self.groups[direction] = dict(flat=main, views=views, params=[e[3] for e in mine],
                                           ptrs=[e[3].data_ptr() for e in mine], versions=None)
+        # one device table, the forward descriptors first: a training step repacks both directions in one launch
+        desc = torch.tensor(tables["fwd"] + tables["bwd"], dtype=torch.int64).to(device)
+        nf = len(tables["fwd"])
+        self.groups["fwd"]["desc"], self.groups["bwd"]["desc"] = desc[:nf], desc[nf:]
 
 
 def lunext_packer_for(module, device):
