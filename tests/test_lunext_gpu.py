@@ -215,7 +215,9 @@ def yardstick(o, what, min_numel=1, skip=()):
 
 
 @pytest.mark.parametrize("B,C,H,W,loss", [(4, 3, 64, 64, "cldice"), (2, 3, 48, 80, "bce"), (2, 2, 32, 32, "bce"),
-                                          (2, 3, 128, 128, "cldice")])
+                                          (2, 3, 128, 128, "cldice"),
+                                          # 8 input channels fill the first level (no padded bias), 1 is the other end
+                                          (2, 8, 64, 64, "bce"), (2, 1, 64, 64, "bce")])
 def test_lunext_train_step_matches_oracle(B, C, H, W, loss):
     o = three_way(B, C, H, W, loss)
     err, scale = yardstick(o, f"{B}x{C}x{H}x{W} {loss}")

@@ -49,3 +49,15 @@ def test_unet_plan_covers_every_gemm_layer_once_per_direction():
         assert N * T * K == p.numel(), name
         assert _extent(N, T, K, on, ot) == N * T * K, name        # dense [N][T][K] operand
         assert (N - 1) * sn + (T - 1) * st + (K - 1) * sk == p.numel() - 1, name
+
+
+def test_lunext_plan_refuses_more_than_eight_input_channels():
+    import pytest
+    with pytest.raises(ValueError):
+        packing.lunext_pack_plan(unet_amd.LUNeXt(9, 1))
+    for cin in (1, 3, 8):                                         # what the 8-channel first level carries
+        sizes, entries = packing.lunext_pack_plan(unet_amd.LUNeXt(cin, 2))
+        assert sizes["fwd"]["head.w.f32"] == 16 and sizes["fwd"]["att4.gate8.f32"] == 216
+        assert ("up4.bias.f32" in sizes["fwd"]) == (cin != 8)
+        for (d, key, off, p, N, T, K, sn, st, sk, on, ot) in entries:
+            assert off + (N - 1) * on + (T - 1) * ot + K <= sizes[d][key], (cin, key)

@@ -95,6 +95,8 @@ def lunext_pack_plan(module):
     and the repack writes the real entries only.  Keys ending in ".f32" are fp32 tables (the zero-padded parameters of
     the 8-channel vector kernels), written by the same launch."""
     chans = [module.in_channels, 64, 128, 256, 512]
+    if chans[0] > 8:
+        raise ValueError(f"LUNeXt's first level is carried as 8 channels: in_channels={chans[0]} is not supported")
     cp = [max(8, (c + 7) // 8 * 8) for c in chans]
     sizes = {"fwd": {}, "bwd": {}}
     entries = []
